@@ -1,0 +1,739 @@
+// fsmc_capi.hip -- host side of libfastsmc_hip.so: the C ABI of include/fastsmc_hip.h.
+//
+// Owns device memory (model tables, packed haplotypes, work list, per-wave workspace, record
+// buffer), validates every shape on the host before a launch (an out-of-bounds kernel can take
+// the whole node down), picks the chunking of the beta stream, launches the decode kernel and
+// orders the results the way the reference writes them.  No CPU fallback exists: if HIP is not
+// usable every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fsmc_kernels.h"
+
+using namespace fsmc;
+
+namespace
+{
+thread_local std::string g_createError;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+} // namespace
+
+struct fsmc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool ownStream = false;
+  int nCU = 0;
+  uint64_t hbmBytes = 0;
+  uint64_t wsLimit = 0;
+  std::string err;
+
+  unsigned long long* dHaps = nullptr;
+  uint32_t nHaps = 0, nSites = 0, W = 0;
+
+  fsmc_pair* dPairs = nullptr;
+  fsmc_group* dGroups = nullptr;
+  size_t nPairs = 0, nGroups = 0;
+  std::vector<fsmc_pair> hPairs;
+  std::vector<fsmc_group> hGroups;
+
+  unsigned* dCounters = nullptr;
+  DevBuf ws;
+  DevBuf recs;
+  size_t recCap = 0;
+  DevBuf aux;  // dump offsets
+  DevBuf out;  // device-side result staging (dump / per-pair / sums)
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int lastSlots = 0;
+
+  const fsmc_model* ibdModel = nullptr;
+  uint32_t ibdFlags = 0;
+  bool ibdPending = false;
+};
+
+struct fsmc_model {
+  fsmc_ctx* ctx = nullptr;
+  int K = 0, KP = 0, S = 0, nRows = 0;
+  float *pi = nullptr, *cR = nullptr, *expT = nullptr;
+  float *D = nullptr, *B = nullptr, *U = nullptr, *RR = nullptr;
+  int* stepRow = nullptr;
+  float4* emis3 = nullptr;
+  unsigned stateThr = 0, ageThr = 0;
+  float probThr = 0.f;
+};
+
+namespace
+{
+
+int fail(fsmc_ctx* ctx, int code, const std::string& msg)
+{
+  if (ctx) {
+    ctx->err = msg;
+  } else {
+    g_createError = msg;
+  }
+  return code;
+}
+
+#define FSMC_HIP(ctx, call)                                                                                            \
+  do {                                                                                                                 \
+    hipError_t e_ = (call);                                                                                            \
+    if (e_ != hipSuccess) {                                                                                            \
+      return fail((ctx), FSMC_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));                                \
+    }                                                                                                                  \
+  } while (0)
+
+int ensure(fsmc_ctx* ctx, DevBuf& b, size_t bytes)
+{
+  if (b.bytes >= bytes && b.p) {
+    return FSMC_OK;
+  }
+  if (b.p) {
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  if (bytes == 0) {
+    bytes = 16;
+  }
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return fail(ctx, FSMC_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+  }
+  b.bytes = bytes;
+  return FSMC_OK;
+}
+
+template <typename T> int upload(fsmc_ctx* ctx, T** dst, const T* src, size_t n)
+{
+  if (*dst) {
+    (void)hipFree(*dst);
+    *dst = nullptr;
+  }
+  hipError_t e = hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) {
+    *dst = nullptr;
+    return fail(ctx, FSMC_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  }
+  if (n) {
+    FSMC_HIP(ctx, hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return FSMC_OK;
+}
+
+// rows padded to KP floats so that every table row starts 16-byte aligned
+std::vector<float> padRows(const float* src, size_t rows, int K, int KP)
+{
+  std::vector<float> out(rows * (size_t)KP, 0.f);
+  for (size_t r = 0; r < rows; ++r) {
+    std::memcpy(&out[r * KP], src + r * K, sizeof(float) * (size_t)K);
+  }
+  return out;
+}
+
+using KernelFn = void (*)(const KParams);
+
+template <int MODE, bool TRACK> KernelFn pickKernel(int K)
+{
+  switch (K) {
+  case 69:
+    return decode_kernel<69, MODE, TRACK>;
+  default:
+    return decode_kernel<0, MODE, TRACK>;
+  }
+}
+
+KernelFn pickKernel(int mode, bool track, int K)
+{
+  switch (mode) {
+  case kModeIbd:
+    return track ? pickKernel<kModeIbd, true>(K) : pickKernel<kModeIbd, false>(K);
+  case kModeDump:
+    return pickKernel<kModeDump, false>(K);
+  default:
+    return nullptr;
+  }
+}
+
+struct LaunchPlan {
+  int chunk = 0;
+  int maxChunks = 0;
+  size_t wsSlot = 0; // float4 per slot
+  int slots = 0;
+};
+
+// Decide chunking of the beta stream and the number of resident waves.
+int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan)
+{
+  int blocksPerCU = 0;
+  FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fn, kWave, 0));
+  if (blocksPerCU < 1) {
+    blocksPerCU = 1;
+  }
+  if (blocksPerCU > 8) {
+    blocksPerCU = 8;
+  }
+  size_t slots = (size_t)ctx->nCU * blocksPerCU;
+  slots = std::min(slots, ctx->nGroups);
+  if (slots < 1) {
+    slots = 1;
+  }
+  size_t L = 1;
+  for (const fsmc_group& g : ctx->hGroups) {
+    const size_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
+    L = std::max<size_t>(L, aEnd - g.from);
+  }
+  const size_t K4 = (size_t)(m->K + 3) / 4;
+  const size_t vecBytes = K4 * kWave * sizeof(float4);
+  const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes);
+  size_t C, maxChunks;
+  if ((L + 5) * vecBytes * slots <= limit) {
+    C = L;
+    maxChunks = 1;
+  } else {
+    C = (size_t)std::ceil(std::sqrt((double)L));
+    C = (C + 15) / 16 * 16;
+    maxChunks = (L + C - 1) / C;
+    if ((C + maxChunks + 5) * vecBytes * slots > limit) {
+      return fail(ctx, FSMC_ENOMEM, "workspace limit too small for the decode window");
+    }
+  }
+  plan.chunk = (int)C;
+  plan.maxChunks = (int)maxChunks;
+  plan.wsSlot = (C + maxChunks + 2 + 2) * K4 * kWave;
+  plan.slots = (int)slots;
+  return ensure(ctx, ctx->ws, plan.wsSlot * sizeof(float4) * slots);
+}
+
+int checkReady(fsmc_ctx* ctx, const fsmc_model* m)
+{
+  if (!ctx || !m) {
+    return fail(ctx, FSMC_EINVAL, "null context or model");
+  }
+  if (m->ctx != ctx) {
+    return fail(ctx, FSMC_EINVAL, "model belongs to another context");
+  }
+  if (!ctx->dHaps) {
+    return fail(ctx, FSMC_ESTATE, "no haplotypes uploaded (fsmc_haps_upload)");
+  }
+  if (!ctx->dPairs || !ctx->dGroups || ctx->nGroups == 0) {
+    return fail(ctx, FSMC_ESTATE, "no work list uploaded (fsmc_worklist_upload)");
+  }
+  if ((uint32_t)m->S != ctx->nSites) {
+    return fail(ctx, FSMC_EINVAL, "model has " + std::to_string(m->S) + " sites but haplotypes have " +
+                                      std::to_string(ctx->nSites));
+  }
+  for (const fsmc_pair& pr : ctx->hPairs) {
+    if (pr.hap_a >= ctx->nHaps || pr.hap_b >= ctx->nHaps) {
+      return fail(ctx, FSMC_EINVAL, "pair refers to a haplotype row outside the uploaded matrix");
+    }
+  }
+  for (const fsmc_group& g : ctx->hGroups) {
+    if (g.to > (uint32_t)m->S) {
+      return fail(ctx, FSMC_EINVAL, "group window exceeds the number of sites");
+    }
+  }
+  if (m->K > kMaxGenericK) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxGenericK) + " states");
+  }
+  return FSMC_OK;
+}
+
+void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan, uint32_t flags, KParams& p)
+{
+  std::memset(&p, 0, sizeof(p));
+  p.K = m->K;
+  p.KP = m->KP;
+  p.S = m->S;
+  p.W = (int)ctx->W;
+  p.nGroups = (int)ctx->nGroups;
+  p.chunk = plan.chunk;
+  p.maxChunks = plan.maxChunks;
+  p.flags = flags;
+  p.pi = m->pi;
+  p.cR = m->cR;
+  p.expT = m->expT;
+  p.D = m->D;
+  p.B = m->B;
+  p.U = m->U;
+  p.RR = m->RR;
+  p.stepRow = m->stepRow;
+  p.emis3 = m->emis3;
+  p.haps = ctx->dHaps;
+  p.pairs = ctx->dPairs;
+  p.groups = ctx->dGroups;
+  p.counters = ctx->dCounters;
+  p.ws = (float4*)ctx->ws.p;
+  p.wsSlot = plan.wsSlot;
+  p.stateThr = m->stateThr;
+  p.ageThr = m->ageThr;
+  // int * float, evaluated in fp32 like HMM.cpp:1226,1254,1281,1308
+  p.thr[0] = 1000 * m->probThr;
+  p.thr[1] = 100 * m->probThr;
+  p.thr[2] = 10 * m->probThr;
+  p.thr[3] = m->probThr;
+  p.recs = (fsmc_ibd_record*)ctx->recs.p;
+  p.recCap = (unsigned)ctx->recCap;
+}
+
+int launch(fsmc_ctx* ctx, KernelFn fn, const KParams& p, int slots)
+{
+  FSMC_HIP(ctx, hipMemsetAsync(ctx->dCounters, 0, 4 * sizeof(unsigned), ctx->stream));
+  FSMC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(fn, dim3((unsigned)slots), dim3(kWave), 0, ctx->stream, p);
+  FSMC_HIP(ctx, hipGetLastError());
+  FSMC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->timed = true;
+  ctx->lastSlots = slots;
+  return FSMC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* fsmc_last_error(const fsmc_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : g_createError.c_str();
+}
+
+int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
+{
+  if (!out) {
+    return fail(nullptr, FSMC_EINVAL, "out is null");
+  }
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    return fail(nullptr, FSMC_ENODEVICE,
+                std::string("no HIP device available (") + (e == hipSuccess ? "count = 0" : hipGetErrorString(e)) +
+                    "); this library has no CPU fallback");
+  }
+  if (device_id < 0 || device_id >= n) {
+    return fail(nullptr, FSMC_EINVAL, "device_id out of range");
+  }
+  fsmc_ctx* ctx = new (std::nothrow) fsmc_ctx();
+  if (!ctx) {
+    return fail(nullptr, FSMC_ENOMEM, "host allocation failed");
+  }
+  ctx->device = device_id;
+  e = hipSetDevice(device_id);
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) {
+    e = hipGetDeviceProperties(&prop, device_id);
+  }
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, FSMC_ENODEVICE, std::string("hipSetDevice/hipGetDeviceProperties: ") + hipGetErrorString(e));
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string arch = prop.gcnArchName;
+    delete ctx;
+    return fail(nullptr, FSMC_ENODEVICE, "device is " + arch + "; this library is built for gfx950 (MI355X) only");
+  }
+  ctx->nCU = prop.multiProcessorCount;
+  ctx->hbmBytes = (uint64_t)prop.totalGlobalMem;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    ctx->ownStream = (e == hipSuccess);
+  }
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->dCounters, 4 * sizeof(unsigned));
+  if (e != hipSuccess) {
+    std::string msg = std::string("context set-up failed: ") + hipGetErrorString(e);
+    fsmc_ctx_destroy(ctx);
+    return fail(nullptr, FSMC_EHIP, msg);
+  }
+  *out = ctx;
+  return FSMC_OK;
+}
+
+void fsmc_ctx_destroy(fsmc_ctx* ctx)
+{
+  if (!ctx) {
+    return;
+  }
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (ctx->dHaps) (void)hipFree(ctx->dHaps);
+  if (ctx->dPairs) (void)hipFree(ctx->dPairs);
+  if (ctx->dGroups) (void)hipFree(ctx->dGroups);
+  if (ctx->dCounters) (void)hipFree(ctx->dCounters);
+  if (ctx->ws.p) (void)hipFree(ctx->ws.p);
+  if (ctx->recs.p) (void)hipFree(ctx->recs.p);
+  if (ctx->aux.p) (void)hipFree(ctx->aux.p);
+  if (ctx->out.p) (void)hipFree(ctx->out.p);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int fsmc_ctx_info(const fsmc_ctx* ctx, int32_t* n_cu, int32_t* n_slots, uint64_t* hbm_bytes)
+{
+  if (!ctx) {
+    return FSMC_EINVAL;
+  }
+  if (n_cu) *n_cu = ctx->nCU;
+  if (n_slots) *n_slots = ctx->lastSlots;
+  if (hbm_bytes) *hbm_bytes = ctx->hbmBytes;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes)
+{
+  if (!ctx) {
+    return FSMC_EINVAL;
+  }
+  ctx->wsLimit = bytes;
+  return FSMC_OK;
+}
+
+int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
+{
+  if (!ctx || !d || !out) {
+    return fail(ctx, FSMC_EINVAL, "null argument");
+  }
+  *out = nullptr;
+  if (d->K < 2 || d->S < 1 || d->n_rows < 1) {
+    return fail(ctx, FSMC_EINVAL, "need K >= 2, S >= 1, n_rows >= 1");
+  }
+  if (d->K > kMaxGenericK) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxGenericK) + " states");
+  }
+  if (!d->pi || !d->col_ratios || !d->exp_times || !d->D || !d->B || !d->U || !d->RR || !d->step_row || !d->e1 ||
+      !d->e0m1 || !d->e2m0) {
+    return fail(ctx, FSMC_EINVAL, "null table pointer in model description");
+  }
+  if (d->state_threshold > (uint32_t)d->K || d->age_threshold > (uint32_t)d->K) {
+    return fail(ctx, FSMC_EINVAL, "state/age threshold larger than K");
+  }
+  for (int32_t s = 1; s < d->S; ++s) {
+    if (d->step_row[s] < 0 || d->step_row[s] >= d->n_rows) {
+      return fail(ctx, FSMC_EINVAL, "step_row[" + std::to_string(s) + "] outside the transition tables");
+    }
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  fsmc_model* m = new (std::nothrow) fsmc_model();
+  if (!m) {
+    return fail(ctx, FSMC_ENOMEM, "host allocation failed");
+  }
+  m->ctx = ctx;
+  m->K = d->K;
+  m->KP = (d->K + 3) / 4 * 4;
+  m->S = d->S;
+  m->nRows = d->n_rows;
+  m->stateThr = d->state_threshold;
+  m->ageThr = d->age_threshold;
+  m->probThr = d->probability_threshold;
+  const int K = m->K, KP = m->KP;
+  int rc = FSMC_OK;
+  auto up = [&](float** dst, const float* src, size_t rows) {
+    if (rc == FSMC_OK) {
+      std::vector<float> padded = padRows(src, rows, K, KP);
+      rc = upload(ctx, dst, padded.data(), padded.size());
+    }
+  };
+  up(&m->pi, d->pi, 1);
+  up(&m->cR, d->col_ratios, 1);
+  up(&m->expT, d->exp_times, 1);
+  up(&m->D, d->D, (size_t)d->n_rows);
+  up(&m->B, d->B, (size_t)d->n_rows);
+  up(&m->U, d->U, (size_t)d->n_rows);
+  up(&m->RR, d->RR, (size_t)d->n_rows);
+  if (rc == FSMC_OK) {
+    std::vector<int> rows(d->step_row, d->step_row + d->S);
+    rows[0] = 0;
+    rc = upload(ctx, &m->stepRow, rows.data(), rows.size());
+  }
+  if (rc == FSMC_OK) {
+    // The reference evaluates e = (e1 + e0m1*isZero) + e2m0*isTwo with isZero/isTwo in {0,1}
+    // (HMM.cpp:827-828, 959-961).  The three reachable (isZero,isTwo) combinations are tabulated
+    // here with the same fp32 expression, so the kernel's row select is bit-identical.
+    std::vector<float> emis((size_t)d->S * 3 * KP, 0.f);
+    static const float zs[3] = {0.f, 1.f, 1.f};
+    static const float ts[3] = {0.f, 0.f, 1.f};
+    for (int32_t s = 0; s < d->S; ++s) {
+      for (int c = 0; c < 3; ++c) {
+        float* dst = &emis[((size_t)s * 3 + c) * KP];
+        const volatile float z = zs[c];
+        const volatile float t = ts[c];
+        for (int k = 0; k < K; ++k) {
+          const size_t i = (size_t)s * K + k;
+          dst[k] = d->e1[i] + d->e0m1[i] * z + d->e2m0[i] * t;
+        }
+      }
+    }
+    rc = upload(ctx, (float**)&m->emis3, emis.data(), emis.size());
+  }
+  if (rc != FSMC_OK) {
+    fsmc_model_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return FSMC_OK;
+}
+
+void fsmc_model_destroy(fsmc_model* m)
+{
+  if (!m) {
+    return;
+  }
+  if (m->ctx) {
+    (void)hipSetDevice(m->ctx->device);
+    if (m->ctx->ibdModel == m) {
+      m->ctx->ibdModel = nullptr;
+    }
+  }
+  float* ptrs[] = {m->pi, m->cR, m->expT, m->D, m->B, m->U, m->RR, (float*)m->emis3};
+  for (float* q : ptrs) {
+    if (q) (void)hipFree(q);
+  }
+  if (m->stepRow) (void)hipFree(m->stepRow);
+  delete m;
+}
+
+int fsmc_haps_upload(fsmc_ctx* ctx, const uint64_t* bits, uint32_t n_haps, uint32_t n_sites)
+{
+  if (!ctx || !bits || n_haps == 0 || n_sites == 0) {
+    return fail(ctx, FSMC_EINVAL, "null or empty haplotype matrix");
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t W = (n_sites + 63u) / 64u;
+  int rc = upload(ctx, &ctx->dHaps, (const unsigned long long*)bits, (size_t)n_haps * W);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  ctx->nHaps = n_haps;
+  ctx->nSites = n_sites;
+  ctx->W = W;
+  return FSMC_OK;
+}
+
+int fsmc_worklist_upload(fsmc_ctx* ctx, const fsmc_pair* pairs, size_t n_pairs, const fsmc_group* groups,
+                         size_t n_groups)
+{
+  if (!ctx || !pairs || !groups || n_pairs == 0 || n_groups == 0) {
+    return fail(ctx, FSMC_EINVAL, "null or empty work list");
+  }
+  if (n_pairs > 0xFFFFFFF0ull) {
+    return fail(ctx, FSMC_EINVAL, "too many pairs for one work list");
+  }
+  size_t covered = 0;
+  for (size_t g = 0; g < n_groups; ++g) {
+    const fsmc_group& G = groups[g];
+    if (G.n_pairs < 1 || G.n_pairs > (uint32_t)kWave) {
+      return fail(ctx, FSMC_EINVAL, "group " + std::to_string(g) + ": n_pairs must be 1..64");
+    }
+    if (G.first_pair != covered) {
+      return fail(ctx, FSMC_EINVAL, "group " + std::to_string(g) + ": groups must partition the pair list in order");
+    }
+    if (!(G.from < G.to) || !(G.from <= G.scan_from && G.scan_from < G.scan_to && G.scan_to <= G.to)) {
+      return fail(ctx, FSMC_EINVAL, "group " + std::to_string(g) + ": need from <= scan_from < scan_to <= to");
+    }
+    covered += G.n_pairs;
+  }
+  if (covered != n_pairs) {
+    return fail(ctx, FSMC_EINVAL, "groups cover " + std::to_string(covered) + " pairs, list has " +
+                                      std::to_string(n_pairs));
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = upload(ctx, &ctx->dPairs, pairs, n_pairs);
+  if (rc == FSMC_OK) {
+    rc = upload(ctx, &ctx->dGroups, groups, n_groups);
+  }
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  ctx->nPairs = n_pairs;
+  ctx->nGroups = n_groups;
+  ctx->hPairs.assign(pairs, pairs + n_pairs);
+  ctx->hGroups.assign(groups, groups + n_groups);
+  ctx->ibdPending = false;
+  return FSMC_OK;
+}
+
+int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
+{
+  int rc = checkReady(ctx, m);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  const bool track = (flags & (FSMC_WANT_MEAN | FSMC_WANT_MAP)) != 0;
+  KernelFn fn = pickKernel(kModeIbd, track, m->K);
+  LaunchPlan plan;
+  rc = planLaunch(ctx, m, kModeIbd, fn, plan);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  if (ctx->recCap == 0) {
+    ctx->recCap = std::max<size_t>(1u << 16, 8 * ctx->nPairs);
+  }
+  rc = ensure(ctx, ctx->recs, ctx->recCap * sizeof(fsmc_ibd_record));
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  KParams p;
+  fillParams(ctx, m, plan, flags, p);
+  rc = launch(ctx, fn, p, plan.slots);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  ctx->ibdModel = m;
+  ctx->ibdFlags = flags;
+  ctx->ibdPending = true;
+  return FSMC_OK;
+}
+
+int fsmc_sync(fsmc_ctx* ctx)
+{
+  if (!ctx) {
+    return FSMC_EINVAL;
+  }
+  FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FSMC_OK;
+}
+
+int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms)
+{
+  if (!ctx || !ms) {
+    return FSMC_EINVAL;
+  }
+  if (!ctx->timed) {
+    return fail(ctx, FSMC_ESTATE, "no launch has been timed yet");
+  }
+  FSMC_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  FSMC_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return FSMC_OK;
+}
+
+int fsmc_decode_ibd_fetch(fsmc_ctx* ctx, fsmc_ibd_record* out, size_t cap, size_t* n_out)
+{
+  if (!ctx || !n_out) {
+    return fail(ctx, FSMC_EINVAL, "null argument");
+  }
+  if (!ctx->ibdPending || !ctx->ibdModel) {
+    return fail(ctx, FSMC_ESTATE, "no IBD decode in flight");
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned counters[4] = {0, 0, 0, 0};
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FSMC_HIP(ctx, hipMemcpy(counters, ctx->dCounters, sizeof(counters), hipMemcpyDeviceToHost));
+    if (counters[1] <= ctx->recCap) {
+      break;
+    }
+    // the device buffer was too small: grow it and decode again (results are deterministic)
+    ctx->recCap = (size_t)counters[1] + (size_t)counters[1] / 8 + 1024;
+    int rc = fsmc_decode_ibd_launch(ctx, ctx->ibdModel, ctx->ibdFlags);
+    if (rc != FSMC_OK) {
+      return rc;
+    }
+  }
+  const size_t n = counters[1];
+  if (n > ctx->recCap) {
+    return fail(ctx, FSMC_EHIP, "record buffer still too small after regrowing");
+  }
+  *n_out = n;
+  if (n > cap || (n && !out)) {
+    return fail(ctx, FSMC_EOVERFLOW, "output buffer holds " + std::to_string(cap) + " records, need " +
+                                         std::to_string(n));
+  }
+  if (n) {
+    FSMC_HIP(ctx, hipMemcpy(out, ctx->recs.p, n * sizeof(fsmc_ibd_record), hipMemcpyDeviceToHost));
+    // the reference writes batch by batch, pair by pair, site by site (HMM.cpp:1181,1206)
+    std::sort(out, out + n, [](const fsmc_ibd_record& x, const fsmc_ibd_record& y) {
+      return x.pair != y.pair ? x.pair < y.pair : x.start < y.start;
+    });
+  }
+  return FSMC_OK;
+}
+
+int fsmc_decode_ibd(fsmc_ctx* ctx, const fsmc_model* m, const fsmc_pair* pairs, size_t n_pairs,
+                    const fsmc_group* groups, size_t n_groups, uint32_t flags, fsmc_ibd_record* out, size_t cap,
+                    size_t* n_out)
+{
+  int rc = fsmc_worklist_upload(ctx, pairs, n_pairs, groups, n_groups);
+  if (rc == FSMC_OK) {
+    rc = fsmc_decode_ibd_launch(ctx, m, flags);
+  }
+  if (rc == FSMC_OK) {
+    rc = fsmc_decode_ibd_fetch(ctx, out, cap, n_out);
+  }
+  return rc;
+}
+
+int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_t out_floats)
+{
+  int rc = checkReady(ctx, m);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  if (!out) {
+    return fail(ctx, FSMC_EINVAL, "out is null");
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<size_t> offsets(ctx->nGroups);
+  size_t total = 0;
+  for (size_t g = 0; g < ctx->nGroups; ++g) {
+    offsets[g] = total;
+    total += (size_t)kWave * m->K * (ctx->hGroups[g].to - ctx->hGroups[g].from);
+  }
+  if (total > out_floats) {
+    return fail(ctx, FSMC_EOVERFLOW, "posterior dump needs " + std::to_string(total) + " floats");
+  }
+  KernelFn fn = pickKernel(kModeDump, false, m->K);
+  LaunchPlan plan;
+  rc = planLaunch(ctx, m, kModeDump, fn, plan);
+  if (rc == FSMC_OK) rc = ensure(ctx, ctx->aux, offsets.size() * sizeof(size_t));
+  if (rc == FSMC_OK) rc = ensure(ctx, ctx->out, total * sizeof(float));
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  FSMC_HIP(ctx, hipMemcpyAsync(ctx->aux.p, offsets.data(), offsets.size() * sizeof(size_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+  KParams p;
+  fillParams(ctx, m, plan, 0, p);
+  p.dumpOut = (float*)ctx->out.p;
+  p.dumpOffsets = (const size_t*)ctx->aux.p;
+  rc = launch(ctx, fn, p, plan.slots);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FSMC_HIP(ctx, hipMemcpy(out, ctx->out.p, total * sizeof(float), hipMemcpyDeviceToHost));
+  return FSMC_OK;
+}
+
+int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model*, const float*, float*, int32_t*)
+{
+  return fail(ctx, FSMC_EUNSUPPORTED, "fsmc_decode_per_pair: not built yet");
+}
+
+int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model*, float*, float*, float*, float*)
+{
+  return fail(ctx, FSMC_EUNSUPPORTED, "fsmc_decode_sums: not built yet");
+}
+
+} // extern "C"

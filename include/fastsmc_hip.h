@@ -1,0 +1,153 @@
+/*
+ * fastsmc_hip.h -- C ABI of the MI355X (gfx950) pairwise-HMM decode library, libfastsmc_hip.so.
+ *
+ * This is the drop-in seam for ONE path of PalamaraLab/FastSMC: the batched pairwise HMM
+ * decode (forward, backward, posterior combine) and its posterior consumers.  The reference
+ * has no FFI for this path -- it is private methods of class HMM -- so each entry point
+ * below names the reference call it stands in for (paths relative to ASMC_SRC/SRC):
+ *
+ *   fsmc_model_create      <- what HMM::HMM leaves behind for the path: DecodingQuantities
+ *                             vectors + prepareEmissions rows        (HMM.cpp:65-127, 159-256)
+ *   fsmc_haps_upload       <- Individual::genotype1/2 bit vectors consumed by makeBits
+ *                                                                    (HMM.cpp:147-157)
+ *   fsmc_decode_ibd        <- decodeBatch + writePerPairOutputFastSMC for every batch of a
+ *                             work list                              (HMM.cpp:575-584, 624-633,
+ *                                                                     639-1041, 1179-1357)
+ *   fsmc_decode_posteriors <- decodeBatch; result = m_alphaBuffer     (HMM.cpp:639-722)
+ *   fsmc_decode_per_pair   <- decodeBatch + writePerPairOutput        (HMM.cpp:1360-1458)
+ *   fsmc_decode_sums       <- decodeBatch + augmentSumOverPairs       (HMM.cpp:1044-1085)
+ *
+ * Conventions: plain C types; host buffers are caller-owned, device buffers library-owned;
+ * every function returns 0 on success or a negative FSMC_E* code and never exits or throws;
+ * fsmc_last_error() describes the last failure of the context (or of context creation when
+ * ctx == NULL).  One context per device; contexts are independent and may be driven from
+ * different host threads/processes (one process per GPU).  There is NO CPU fallback: without
+ * a usable HIP device every call fails with FSMC_ENODEVICE.
+ */
+#ifndef FASTSMC_HIP_H
+#define FASTSMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSMC_OK 0
+#define FSMC_EINVAL (-1)    /* bad argument */
+#define FSMC_ENODEVICE (-2) /* no HIP device / HIP runtime failure at start-up */
+#define FSMC_EHIP (-3)      /* a HIP call failed; see fsmc_last_error */
+#define FSMC_ENOMEM (-4)    /* device or host allocation failed */
+#define FSMC_ESTATE (-5)    /* call sequence error (e.g. decode before upload) */
+#define FSMC_EOVERFLOW (-6) /* caller's output buffer too small; *n_out holds the needed count */
+#define FSMC_EUNSUPPORTED (-7)
+
+typedef struct fsmc_ctx fsmc_ctx;
+typedef struct fsmc_model fsmc_model;
+
+/* Constant inputs of the path.  All pointers are host memory, copied by fsmc_model_create. */
+typedef struct {
+  int32_t K;                /* states                          (DecodingQuantities::states) */
+  int32_t S;                /* sites                           (Data::sites) */
+  const float* pi;          /* [K] initialStateProb */
+  const float* col_ratios;  /* [K] columnRatios, zero padded   (DecodingQuantities.cpp:299-303) */
+  const float* exp_times;   /* [K] expectedTimes */
+  int32_t n_rows;           /* rows of the four transition tables */
+  const float* D;           /* [n_rows][K] Dvectors */
+  const float* B;           /* [n_rows][K] Bvectors   (column K-1 unused) */
+  const float* U;           /* [n_rows][K] Uvectors   (column K-1 unused) */
+  const float* RR;          /* [n_rows][K] rowRatioVectors (column K-1 unused) */
+  const int32_t* step_row;  /* [S] table row of key roundMorgans(gen[p]-gen[p-1]) for p>=1 (HMM.cpp:755,909) */
+  const float* e1;          /* [S][K] emission1AtSite */
+  const float* e0m1;        /* [S][K] emission0minus1AtSite */
+  const float* e2m0;        /* [S][K] emission2minus0AtSite */
+  uint32_t state_threshold; /* HMM::stateThreshold      (HMM.cpp:504-513) */
+  uint32_t age_threshold;   /* HMM::ageThreshold        (HMM.cpp:101-105) */
+  float probability_threshold; /* HMM::probabilityThreshold (HMM.cpp:96-99) */
+} fsmc_model_desc;
+
+/* One haplotype pair: rows of the uploaded bit matrix.  Row 2*ind + (hap-1). */
+typedef struct {
+  uint32_t hap_a; /* the record's first haplotype  (PairObservations iInd/iHap) */
+  uint32_t hap_b; /* the record's second haplotype (PairObservations jInd/jHap) */
+} fsmc_pair;
+
+/* A batch of <= 64 consecutive pairs that share one decode window -- the reference's batch
+ * (HMM.cpp:555-636).  [from,to) is the padded decode window handed to decodeBatch;
+ * [scan_from,scan_to) is the window the IBD scan covers (HMM.cpp:1199-1206).  Non-hashing
+ * mode: from = scan_from = 0, to = scan_to = S. */
+typedef struct {
+  uint32_t first_pair; /* index into the pair list */
+  uint32_t n_pairs;    /* 1..64 */
+  uint32_t from, to;
+  uint32_t scan_from, scan_to;
+} fsmc_group;
+
+/* One IBD segment as handed to HMM::writePairIBD (HMM.cpp:1110-1177). */
+typedef struct {
+  uint32_t pair;   /* index into the pair list */
+  int32_t start;   /* first site */
+  int32_t end;     /* last site, inclusive */
+  float prob;      /* cumulative posterior ("posteriorIBD"); ibd_score = prob / (end-start+1) */
+  float post_mean; /* getPosteriorMean of the per-state sums (0 if not requested) */
+  float map;       /* getMAP of the per-state sums (0 if not requested) */
+} fsmc_ibd_record;
+
+#define FSMC_WANT_MEAN 1u /* DecodingParams::doPerPairPosteriorMean */
+#define FSMC_WANT_MAP 2u  /* DecodingParams::doPerPairMAP */
+#define FSMC_WANT_SUMS 4u /* DecodingParams::doPosteriorSums (fsmc_decode_sums) */
+#define FSMC_WANT_MAJOR_MINOR_SUMS 8u /* doMajorMinorPosteriorSums */
+
+/* ---- context ---- */
+/* stream: an existing hipStream_t to launch on (e.g. torch's current stream), or NULL for a private one. */
+int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out);
+void fsmc_ctx_destroy(fsmc_ctx* ctx);
+const char* fsmc_last_error(const fsmc_ctx* ctx);
+/* Device properties as seen by the library: CU count, and the number of resident decode waves it launches. */
+int fsmc_ctx_info(const fsmc_ctx* ctx, int32_t* n_cu, int32_t* n_slots, uint64_t* hbm_bytes);
+/* Cap on the workspace the library may allocate for alpha/beta streaming (bytes; 0 = default 40 % of HBM). */
+int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes);
+
+/* ---- resident inputs ---- */
+int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* desc, fsmc_model** out);
+void fsmc_model_destroy(fsmc_model* m);
+/* bits: [n_haps][ceil(n_sites/64)] little-endian words, site s at bit (s % 64) of word s / 64. */
+int fsmc_haps_upload(fsmc_ctx* ctx, const uint64_t* bits, uint32_t n_haps, uint32_t n_sites);
+/* The work list: pairs and the groups (batches) that partition them in order. */
+int fsmc_worklist_upload(fsmc_ctx* ctx, const fsmc_pair* pairs, size_t n_pairs, const fsmc_group* groups,
+                         size_t n_groups);
+
+/* ---- the hot path, split so that timing can exclude transfers ---- */
+/* Launch the IBD decode of the resident work list (asynchronous on the context's stream). */
+int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags);
+/* Wait, copy back and order the records like the reference writes them (batch, pair in batch, site).
+ * If cap is too small returns FSMC_EOVERFLOW with *n_out = needed. */
+int fsmc_decode_ibd_fetch(fsmc_ctx* ctx, fsmc_ibd_record* out, size_t cap, size_t* n_out);
+/* Block until the stream is idle. */
+int fsmc_sync(fsmc_ctx* ctx);
+/* Device time (ms, hipEvent) of the last decode launch's kernel(s); valid after a sync/fetch. */
+int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms);
+
+/* Convenience: upload work list + launch + fetch. */
+int fsmc_decode_ibd(fsmc_ctx* ctx, const fsmc_model* m, const fsmc_pair* pairs, size_t n_pairs,
+                    const fsmc_group* groups, size_t n_groups, uint32_t flags, fsmc_ibd_record* out, size_t cap,
+                    size_t* n_out);
+
+/* Posterior of every pair of the resident work list over its group's window, in the reference's batch layout
+ * per group: out[group][pos - from][k][lane 0..63], i.e. group g starts at out + offsets[g] floats where
+ * offsets[g] = 64*K*sum_{h<g}(to_h - from_h).  Lanes >= n_pairs are zero.  out_floats = capacity of out. */
+int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_t out_floats);
+
+/* writePerPairOutput: mean[n_pairs][S] = sum_k post*exp_times[k]; map[n_pairs][S] = first argmax_k post.
+ * Either may be NULL.  Requires whole-sequence groups (from = 0, to = S), as in the reference (HMM.cpp:1378). */
+int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model* m, const float* exp_coal_times, float* mean, int32_t* map);
+
+/* augmentSumOverPairs: sums[S][K] += sum over the pairs of the work list of the posterior
+ * (and the 00/01/11 split when the pointers are non-NULL).  Whole-sequence groups only. */
+int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sums00, float* sums01, float* sums11);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
