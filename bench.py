@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- pairs/s of the pairwise HMM decode path on MI355X, against its HBM roofline.
+
+Workload (BASELINE.json configs[1]): synthetic 1000 haplotypes x 50000 sites, 69 states, all
+499500 haplotype pairs, FastSMC-mode output (IBD segments + posterior-mean / MAP ages, no hashing),
+one GPU.  A "step" = one decode of the whole pair list with every input (model tables, packed
+haplotypes, work list) already resident in HBM; the step ends when the ordered IBD records are back
+on the host.  With N > 1 (one process per GPU under torch.distributed.run) every rank decodes the
+full pair list of its own synthetic cohort (seed + rank) -- weak scaling, no data-path collective --
+and the records are gathered to rank 0 over RCCL at the end of each step.
+
+Prints ONE JSON line (see the contract in the task description) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); ~6.3e12 is the measured achievable
+
+
+def build_problem(n_hap: int, n_sites: int, K: int, seed: int):
+    """Synthetic cohort + model, prepared by the product's own host code (C++ Data/HMM constructors)."""
+    from fastsmc_amd import api, synth
+
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(n_hap, n_sites, seed=seed)
+    data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
+    dq = api.decoding_quantities_from_tables(tables)
+    p = api.DecodingParams()
+    # FastSMC defaults (DecodingParams.cpp:56-73) except hashing
+    p.FastSMC = True
+    p.foldData = True
+    p.usingCSFS = True
+    p.batchSize = 32
+    p.time = 50
+    p.noConditionalAgeEstimates = True
+    p.doPerPairPosteriorMean = True
+    p.doPerPairMAP = True
+    p.outputIbdSegmentLength = True
+    p.useKnownSeed = True
+    p.hashing = False
+    hmm = api.HMM(data, dq, p)
+    pm = api.PreparedModelView(hmm.preparedModel())
+    bits = data.packed_bits()
+    return pm, bits, haps, tables
+
+
+def all_pairs(n_ind: int) -> np.ndarray:
+    """Pair order of HMM::decodeAll (HMM.cpp:325-357), vectorised: rows (hapA, hapB)."""
+    out = []
+    for i in range(n_ind):
+        if i:
+            j = np.repeat(np.arange(i, dtype=np.uint32), 4)
+            i_hap = np.tile(np.array([0, 0, 1, 1], np.uint32), i)
+            j_hap = np.tile(np.array([0, 1, 0, 1], np.uint32), i)
+            out.append(np.stack([2 * j + j_hap, np.full(4 * i, 2 * i, np.uint32) + i_hap], axis=1))
+        out.append(np.array([[2 * i, 2 * i + 1]], np.uint32))
+    return np.concatenate(out).astype(np.uint32)
+
+
+def cpu_baseline(pm, haps, n_pairs_sample: int, pairs: np.ndarray) -> dict:
+    """The oracle (C restatement of the reference's NO_SSE path, 1 thread) on the first pairs of the same
+    work list, same sites, reference batch size 32.  Reported baseline only."""
+    from fastsmc_amd import synth
+    from oracle import oracle as O
+
+    _, _, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    model = O.PreparedModel(K=pm.K, S=pm.S, pi=pm.pi, col_ratios=pm.col_ratios, exp_times=pm.exp_times, D=pm.D,
+                            B=pm.B, U=pm.U, RR=pm.RR, step_row=pm.step_row, e1=pm.e1, e0m1=pm.e0m1, e2m0=pm.e2m0,
+                            gen=np.zeros(pm.S, np.float32), phys=np.zeros(pm.S, np.int32),
+                            state_threshold=int(pm.state_threshold), age_threshold=int(pm.age_threshold),
+                            probability_threshold=np.float32(pm.probability_threshold))
+    sample = [tuple(int(x) for x in pr) for pr in pairs[:n_pairs_sample]]
+    t0 = time.perf_counter()
+    recs = O.decode_pairs_ibd(model, folded, sample, batch_size=32)
+    dt = time.perf_counter() - t0
+    return {"value": len(sample) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {len(sample)} pairs of the same work list x {pm.S} sites (batches of 32), "
+                      f"{dt:.1f} s, {len(recs)} IBD records; oracle/hmm_oracle.c, gcc -O2, 1 thread"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--haps", type=int, default=1000)
+    ap.add_argument("--sites", type=int, default=50000)
+    ap.add_argument("--states", type=int, default=69)
+    ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs in the cpu_baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from fastsmc_amd import capi
+
+    pm, bits, haps, _ = build_problem(args.haps, args.sites, args.states, seed=1234 + rank)
+    pairs = all_pairs(args.haps // 2)
+    n_pairs = int(pairs.shape[0])
+    groups = capi.whole_sequence_groups(n_pairs, pm.S, batch=64)
+
+    ctx = capi.Context(local_rank)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    ctx.upload_worklist(pairs.view(capi.PAIR_DTYPE).reshape(-1), groups)
+    flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
+
+    def gather_records(rec: np.ndarray):
+        """The path's only exchange: variable-length IBD records to rank 0 (counts, then padded payload)."""
+        if dist is None:
+            return rec.size
+        cnt = torch.tensor([rec.size], device="cuda", dtype=torch.int64)
+        counts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(counts, cnt)
+        mx = int(max(int(c.item()) for c in counts))
+        payload = torch.zeros(mx * rec.dtype.itemsize, dtype=torch.uint8, device="cuda")
+        if rec.size:
+            payload[: rec.nbytes] = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+        bucket = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        dist.gather(payload, bucket, dst=0)
+        return int(sum(int(c.item()) for c in counts))
+
+    def step():
+        ctx.decode_ibd_launch(model, flags)
+        rec = ctx.decode_ibd_fetch()
+        return rec, gather_records(rec)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    n_rec = 0
+    for _ in range(args.steps):
+        _, n_rec = step()
+        kernel_ms.append(ctx.last_kernel_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = ctx.info()
+    if rank == 0:
+        total_pairs = n_pairs * world * args.steps
+        value = total_pairs / elapsed
+        k_s = float(np.mean(kernel_ms)) / 1e3
+        bytes_per_pair_site = 8 * pm.K + 0.25  # beta row written + read once, + 2 genotype bits
+        algo_bytes = n_pairs * pm.S * bytes_per_pair_site
+        achieved = algo_bytes / k_s
+        out = {
+            "metric": "haplotype-pairs decoded/sec (whole node) + GB/s vs HBM roofline, 69-state HMM",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.haps} haplotypes x {args.sites} sites, K={pm.K}, all "
+                                   f"{n_pairs} pairs per GPU, FastSMC-mode IBD + posterior-mean/MAP ages, no hashing",
+                       "pair_sites_per_s": value * pm.S, "ibd_records_per_step": n_rec,
+                       "resident_waves": info["n_slots"], "n_cu": info["n_cu"]},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel_ms": 1e3 * k_s, "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if args.cpu_pairs > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pm, haps, args.cpu_pairs, pairs)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,523 @@
+// data.cpp -- input surface of the decode path (reference: Data.cpp).  Errors that make the
+// reference print and exit(1) are thrown as std::runtime_error here (a library must not exit).
+#include "data.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <random>
+#include <stdexcept>
+
+#include "util.hpp"
+
+namespace fsmc_host
+{
+
+namespace
+{
+
+std::string findWithSuffix(const std::string& root, const std::vector<std::string>& suffixes, const char* what)
+{
+  for (const std::string& s : suffixes) {
+    if (fileExists(root + s)) {
+      return root + s;
+    }
+  }
+  std::string msg = std::string("ERROR. Could not find ") + what + " file in";
+  for (const std::string& s : suffixes) {
+    msg += " " + root + s;
+  }
+  throw std::runtime_error(msg);
+}
+
+std::string hapsPath(const std::string& root)
+{
+  return findWithSuffix(root, {".hap.gz", ".hap", ".haps.gz", ".haps"}, "hap");
+}
+std::string samplesPath(const std::string& root)
+{
+  return findWithSuffix(root, {".samples", ".sample"}, "sample");
+}
+std::string mapPath(const std::string& root)
+{
+  return findWithSuffix(root, {".map.gz", ".map"}, "map");
+}
+
+bool isSamplesHeader(const std::vector<std::string>& t)
+{
+  return t.size() >= 3 && ((t[0] == "ID_1" && t[1] == "ID_2" && t[2] == "missing") ||
+                           (t[0] == "0" && t[1] == "0" && t[2] == "0"));
+}
+
+// Splits "chr snpID bp alleleA alleleB<rest>" like `stream >> a >> b >> c >> d >> e; getline(rest)`.
+bool splitHapsLine(const std::string& line, std::string (&field)[5], size_t& restBegin)
+{
+  size_t p = 0;
+  const size_t n = line.size();
+  for (int f = 0; f < 5; ++f) {
+    while (p < n && std::isspace(static_cast<unsigned char>(line[p]))) {
+      ++p;
+    }
+    if (p >= n) {
+      return false;
+    }
+    const size_t b = p;
+    while (p < n && !std::isspace(static_cast<unsigned char>(line[p]))) {
+      ++p;
+    }
+    field[f].assign(line, b, p - b);
+  }
+  restBegin = p;
+  return true;
+}
+
+// Data::sampleHypergeometric (Data.cpp:144-160): glibc rand() seeds a libstdc++ mt19937 for std::shuffle.
+int sampleHypergeometric(int populationSize, int numberOfSuccesses, int sampleSize)
+{
+  if (numberOfSuccesses < 0 || numberOfSuccesses > populationSize) {
+    return -1;
+  }
+  std::vector<unsigned short> samplingVector(static_cast<size_t>(populationSize), 0);
+  for (int i = 0; i < numberOfSuccesses; i++) {
+    samplingVector[static_cast<size_t>(i)] = 1;
+  }
+  std::shuffle(samplingVector.begin(), samplingVector.end(), std::mt19937(std::rand()));
+  int ret = 0;
+  for (int i = 0; i < sampleSize; i++) {
+    ret += samplingVector[static_cast<size_t>(i)];
+  }
+  return ret;
+}
+
+} // namespace
+
+int Data::countHapLines(const std::string& inFileRoot)
+{
+  LineReader br(hapsPath(inFileRoot));
+  std::string line;
+  int n = 0;
+  while (br.getline(line)) {
+    n++;
+  }
+  return n;
+}
+
+int Data::countSamplesLines(const std::string& inFileRoot)
+{
+  LineReader br(samplesPath(inFileRoot));
+  std::string line;
+  int n = 0;
+  while (br.getline(line)) {
+    const auto t = splitWhitespace(line);
+    if (t.empty() || isSamplesHeader(t)) {
+      continue;
+    }
+    n++;
+  }
+  return n;
+}
+
+void Data::setupJobWindows(int jobID, int jobs)
+{
+  // Data.cpp:46-80: the job grid is over windows of individuals; window size is the side of a square
+  mJobbing = (jobID != -1) && (jobs != -1);
+  if (!mJobbing) {
+    return;
+  }
+  const double n = static_cast<double>(sampleSize);
+  windowSize = static_cast<int>(std::ceil(std::sqrt((2. * std::pow(n, 2) - n) * 2. / jobs)));
+  if (windowSize % 2 != 0) {
+    windowSize++;
+  }
+  w_i = 1;
+  int cptJob = 1;
+  int cptTotJob = 1;
+  while (cptTotJob < jobID) {
+    w_i++;
+    cptJob += 2;
+    cptTotJob += cptJob;
+  }
+  w_j = static_cast<int>(std::ceil(static_cast<float>(cptJob - (cptTotJob - jobID)) / 2));
+  is_j_above_diag = (cptJob - (cptTotJob - jobID)) % 2 == 1;
+}
+
+bool Data::readSample(unsigned d, int jobID, int jobs) const
+{
+  if (!mJobbing) {
+    return true;
+  }
+  return (d >= static_cast<unsigned>((w_i - 1) * windowSize) / 2 && d < static_cast<unsigned>(w_i * windowSize) / 2) ||
+         (d >= static_cast<unsigned>((w_j - 1) * windowSize) / 2 && d < static_cast<unsigned>(w_j * windowSize) / 2) ||
+         (jobs == jobID && d >= static_cast<unsigned>((w_j - 1) * windowSize) / 2);
+}
+
+void Data::readSamplesList(const std::string& inFileRoot, int jobID, int jobs)
+{
+  LineReader br(samplesPath(inFileRoot));
+  std::string line;
+  unsigned linesProcessed = 0;
+  while (br.getline(line)) {
+    const auto t = splitWhitespace(line);
+    if (t.empty() || isSamplesHeader(t)) {
+      continue;
+    }
+    if (t.size() < 2) {
+      throw std::runtime_error("ERROR: malformed samples line: " + line);
+    }
+    if (readSample(linesProcessed, jobID, jobs)) {
+      FamIDList.push_back(t[0]);
+      IIDList.push_back(t[1]);
+      famAndIndNameList.push_back(t[0] + "\t" + t[1]);
+    }
+    linesProcessed++;
+  }
+}
+
+void Data::allocateBits()
+{
+  wordsPerHap = (static_cast<size_t>(sites) + 63) / 64;
+  bits.assign(numHapRows() * wordsPerHap, 0ull);
+}
+
+Data::Data(const DecodingParams& params)
+{
+  const std::string& root = params.inFileRoot;
+  foldToMinorAlleles = params.foldData;
+  decodingUsesCSFS = params.usingCSFS;
+
+  sites = countHapLines(root);
+  sampleSize = static_cast<unsigned long>(countSamplesLines(root));
+  haploidSampleSize = sampleSize * 2ul;
+  siteWasFlippedDuringFolding.assign(static_cast<size_t>(sites), false);
+
+  if (params.useKnownSeed) {
+    std::srand(1234u);
+  } else {
+    std::random_device rd;
+    std::srand(rd());
+  }
+  setupJobWindows(params.jobInd, params.jobs);
+  readSamplesList(root, params.jobInd, params.jobs);
+  allocateBits();
+  if (params.FastSMC) {
+    const auto geneticMap = readMapFastSMC(root);
+    readHapsFastSMC(root, params.jobInd, params.jobs, geneticMap);
+  } else {
+    readHapsAsmc(root);
+    readMapAsmc(root);
+  }
+}
+
+std::vector<std::pair<unsigned long, double>> Data::readMapFastSMC(const std::string& inFileRoot)
+{
+  // Data.cpp:98-141: columns "bp <ignored> cM"; a row whose first field is not an integer is a header
+  LineReader br(mapPath(inFileRoot));
+  std::vector<std::pair<unsigned long, double>> geneticMap;
+  std::string line;
+  std::string field[3];
+  while (br.getline(line)) {
+    std::stringstream ss(line);
+    ss >> field[0] >> field[1] >> field[2]; // fields keep their previous value on short lines, like the reference
+    if (field[0].empty()) {
+      continue;
+    }
+    try {
+      (void)std::stoi(field[0]);
+    } catch (const std::invalid_argument&) {
+      continue;
+    }
+    geneticMap.emplace_back(std::stol(field[0]), std::stod(field[2]));
+  }
+  if (geneticMap.empty()) {
+    throw std::runtime_error("ERROR: genetic map " + inFileRoot + ".map[.gz] has no usable rows");
+  }
+  return geneticMap;
+}
+
+void Data::addMarker(unsigned long physicalPos, double geneticPos, unsigned pos)
+{
+  // Data.cpp:549-565
+  geneticPositions.push_back(static_cast<float>(geneticPos / 100.f));
+  physicalPositions.push_back(static_cast<int>(physicalPos));
+  if (pos > 0) {
+    const double genDistFromPrevious = geneticPositions[pos] - geneticPositions[pos - 1];
+    const unsigned long physDistFromPrevious =
+        static_cast<unsigned long>(physicalPositions[pos] - physicalPositions[pos - 1]);
+    const float recRate = static_cast<float>(genDistFromPrevious / physDistFromPrevious);
+    if (pos == 1) {
+      recRateAtMarker.push_back(recRate);
+    }
+    recRateAtMarker.push_back(recRate);
+  }
+}
+
+void Data::addMarkerFromMap(unsigned long bp, const std::vector<std::pair<unsigned long, double>>& map,
+                            unsigned& cur, unsigned pos)
+{
+  // Data::readGeneticMap (Data.cpp:523-547): exact hit, before-first, or linear interpolation
+  while (bp > map[cur].first && cur < map.size() - 1) {
+    cur++;
+  }
+  double cm;
+  if (bp >= map[cur].first || cur == 0) {
+    cm = map[cur].second;
+  } else {
+    cm = map[cur - 1].second + (bp - map[cur - 1].first) * (map[cur].second - map[cur - 1].second) /
+                                   (map[cur].first - map[cur - 1].first);
+  }
+  addMarker(bp, cm, pos);
+}
+
+void Data::readHapsFastSMC(const std::string& inFileRoot, int jobID, int jobs,
+                           const std::vector<std::pair<unsigned long, double>>& geneticMap)
+{
+  // Data.cpp:397-521
+  LineReader br(hapsPath(inFileRoot));
+  totalSamplesCount.assign(static_cast<size_t>(sites), 0);
+  derivedAlleleCounts.assign(static_cast<size_t>(sites), 0);
+  std::string line;
+  std::string field[5];
+  unsigned long largestBp = 0;
+  unsigned pos = 0;
+  unsigned curG = 0;
+  const int totalSamples = static_cast<int>(2 * sampleSize);
+  while (br.getline(line)) {
+    size_t rest = 0;
+    if (!splitHapsLine(line, field, rest)) {
+      continue;
+    }
+    const size_t restLen = line.size() - rest;
+    if (!(restLen == 4 * sampleSize || restLen == 4 * sampleSize + 1)) {
+      throw std::runtime_error("ERROR: haps line has wrong length. Length is " + std::to_string(restLen) +
+                               ", but should be 4 * " + std::to_string(sampleSize));
+    }
+    const unsigned long bp = std::stoul(field[2]);
+    if (bp > largestBp) {
+      largestBp = bp;
+    } else {
+      throw std::runtime_error("ERROR: rows in haps data file must be ordered by increasing physical position, but "
+                               "two consecutive values were " + std::to_string(largestBp) + " and " +
+                               std::to_string(bp));
+    }
+    if (pos == 0) {
+      const std::string chr = field[0].substr(0, field[0].find(':'));
+      try {
+        chrNumber = std::stoi(chr);
+      } catch (const std::exception&) {
+        chrNumber = 0;
+      }
+      if (chrNumber <= 0 || chrNumber > 1260) {
+        chrNumber = 0;
+      }
+    }
+    if (pos >= static_cast<unsigned>(sites)) {
+      break;
+    }
+    addMarkerFromMap(bp, geneticMap, curG, pos);
+    const char* a = line.data() + rest;
+    int DAcount = 0;
+    for (unsigned i = 0; i < 2 * sampleSize; i++) {
+      const char c = a[2 * i + 1];
+      if (c == '1') {
+        DAcount++;
+      } else if (c != '0') {
+        throw std::runtime_error("ERROR: hap is not '0' or '1'");
+      }
+    }
+    totalSamplesCount[pos] = totalSamples;
+    const bool minorAlleleValue = foldToMinorAlleles ? (DAcount <= totalSamples - DAcount) : true;
+    siteWasFlippedDuringFolding[pos] = !minorAlleleValue;
+    size_t row = 0;
+    for (unsigned d = 0; d < sampleSize; d++) {
+      if (readSample(d, jobID, jobs)) {
+        for (unsigned h = 0; h < 2; ++h) {
+          const bool isOne = a[2 * (2 * d + h) + 1] == '1';
+          if (isOne == minorAlleleValue) {
+            setBit(row + h, pos);
+          }
+        }
+        row += 2;
+      }
+    }
+    derivedAlleleCounts[pos] = foldToMinorAlleles ? std::min(DAcount, totalSamples - DAcount) : DAcount;
+    pos++;
+  }
+  if (pos != static_cast<unsigned>(sites)) {
+    throw std::runtime_error("ERROR: read " + std::to_string(pos) + " haps rows, expected " + std::to_string(sites));
+  }
+}
+
+void Data::readHapsAsmc(const std::string& inFileRoot)
+{
+  // Data.cpp:320-395: reads the first 2*numIndividuals() haplotype columns and counts alleles over them
+  LineReader br(hapsPath(inFileRoot));
+  totalSamplesCount.assign(static_cast<size_t>(sites), 0);
+  derivedAlleleCounts.assign(static_cast<size_t>(sites), 0);
+  std::string line;
+  std::string field[5];
+  unsigned pos = 0;
+  const unsigned nHap = static_cast<unsigned>(numHapRows());
+  const int totalSamples = static_cast<int>(nHap);
+  while (br.getline(line)) {
+    size_t rest = 0;
+    if (!splitHapsLine(line, field, rest)) {
+      continue;
+    }
+    const size_t restLen = line.size() - rest;
+    if (!(restLen == 4 * sampleSize || restLen == 4 * sampleSize + 1)) {
+      throw std::runtime_error("ERROR: haps line has wrong length. Length is " + std::to_string(restLen) +
+                               ", should be 4*" + std::to_string(numIndividuals()));
+    }
+    if (pos >= static_cast<unsigned>(sites)) {
+      break;
+    }
+    const char* a = line.data() + rest;
+    int DAcount = 0;
+    for (unsigned i = 0; i < nHap; i++) {
+      const char c = a[2 * i + 1];
+      if (c == '1') {
+        DAcount++;
+      } else if (c != '0') {
+        throw std::runtime_error("ERROR: hap is not '0' or '1'");
+      }
+    }
+    totalSamplesCount[pos] = totalSamples;
+    const bool minorAlleleValue = foldToMinorAlleles ? (DAcount <= totalSamples - DAcount) : true;
+    siteWasFlippedDuringFolding[pos] = !minorAlleleValue;
+    for (unsigned i = 0; i < nHap; i++) {
+      if ((a[2 * i + 1] == '1') == minorAlleleValue) {
+        setBit(i, pos);
+      }
+    }
+    derivedAlleleCounts[pos] = foldToMinorAlleles ? std::min(DAcount, totalSamples - DAcount) : DAcount;
+    pos++;
+  }
+  if (pos != static_cast<unsigned>(sites)) {
+    throw std::runtime_error("ERROR: read " + std::to_string(pos) + " haps rows, expected " + std::to_string(sites));
+  }
+}
+
+void Data::readMapAsmc(const std::string& inFileRoot)
+{
+  // Data.cpp:162-210: plink map "chr id cM bp"; gen = stof(cM) / 100.f in float
+  LineReader br(mapPath(inFileRoot));
+  SNP_IDs.assign(static_cast<size_t>(sites), "");
+  geneticPositions.assign(static_cast<size_t>(sites), 0.f);
+  recRateAtMarker.assign(static_cast<size_t>(sites), 0.f);
+  physicalPositions.assign(static_cast<size_t>(sites), 0);
+  std::string line;
+  int pos = 0;
+  while (br.getline(line)) {
+    const auto t = splitWhitespace(line);
+    if (t.size() < 4) {
+      if (t.empty()) {
+        continue;
+      }
+      throw std::runtime_error("ERROR: malformed map line: " + line);
+    }
+    if (pos >= sites) {
+      pos++;
+      break;
+    }
+    SNP_IDs[pos] = t[1];
+    geneticPositions[pos] = refStof(t[2]) / 100.f;
+    physicalPositions[pos] = std::stoi(t[3]);
+    if (pos > 0) {
+      const float genDist = geneticPositions[pos] - geneticPositions[pos - 1];
+      const int physDist = physicalPositions[pos] - physicalPositions[pos - 1];
+      recRateAtMarker[pos] = genDist / physDist;
+    }
+    pos++;
+  }
+  if (pos != sites) {
+    throw std::runtime_error("ERROR. Read " + std::to_string(pos) + " from map file, expected " +
+                             std::to_string(sites));
+  }
+}
+
+Data Data::fromArrays(const uint8_t* alleles, size_t nHaps, size_t nSites, const int64_t* bp, const double* cm,
+                      bool foldToMinor, bool useKnownSeed, int chrNumber)
+{
+  if (nHaps == 0 || nHaps % 2 != 0 || nSites == 0) {
+    throw std::runtime_error("fromArrays: need an even, positive number of haplotypes and at least one site");
+  }
+  Data d;
+  d.foldToMinorAlleles = foldToMinor;
+  d.decodingUsesCSFS = true;
+  d.sites = static_cast<int>(nSites);
+  d.sampleSize = nHaps / 2;
+  d.haploidSampleSize = nHaps;
+  d.chrNumber = chrNumber;
+  d.siteWasFlippedDuringFolding.assign(nSites, false);
+  if (useKnownSeed) {
+    std::srand(1234u);
+  } else {
+    std::random_device rd;
+    std::srand(rd());
+  }
+  d.setupJobWindows(1, 1);
+  for (size_t i = 0; i < nHaps / 2; ++i) {
+    const std::string id = "1_" + std::to_string(i + 1);
+    d.FamIDList.push_back(id);
+    d.IIDList.push_back(id);
+    d.famAndIndNameList.push_back(id + "\t" + id);
+  }
+  d.allocateBits();
+  d.totalSamplesCount.assign(nSites, static_cast<int>(nHaps));
+  d.derivedAlleleCounts.assign(nSites, 0);
+  for (size_t s = 0; s < nSites; ++s) {
+    d.addMarker(static_cast<unsigned long>(bp[s]), cm[s], static_cast<unsigned>(s));
+    int DAcount = 0;
+    for (size_t h = 0; h < nHaps; ++h) {
+      DAcount += alleles[h * nSites + s] ? 1 : 0;
+    }
+    const int total = static_cast<int>(nHaps);
+    const bool minorAlleleValue = foldToMinor ? (DAcount <= total - DAcount) : true;
+    d.siteWasFlippedDuringFolding[s] = !minorAlleleValue;
+    for (size_t h = 0; h < nHaps; ++h) {
+      if ((alleles[h * nSites + s] != 0) == minorAlleleValue) {
+        d.setBit(h, s);
+      }
+    }
+    d.derivedAlleleCounts[s] = foldToMinor ? std::min(DAcount, total - DAcount) : DAcount;
+  }
+  return d;
+}
+
+std::vector<bool> Data::genotypeVector(size_t hapRow) const
+{
+  std::vector<bool> v(static_cast<size_t>(sites));
+  for (size_t s = 0; s < v.size(); ++s) {
+    v[s] = genotype(hapRow, s);
+  }
+  return v;
+}
+
+std::vector<std::vector<int>> Data::calculateUndistinguishedCounts(const int numCsfsSamples) const
+{
+  // Data.cpp:567-599
+  std::vector<std::vector<int>> undistinguished(derivedAlleleCounts.size(), std::vector<int>(3));
+  for (size_t i = 0; i < derivedAlleleCounts.size(); ++i) {
+    const int derivedAlleles = derivedAlleleCounts[i];
+    const int totalSamples = totalSamplesCount[i];
+    if (decodingUsesCSFS && numCsfsSamples > totalSamples) {
+      throw std::runtime_error("ERROR. SNP with numerical ID " + std::to_string(i) + " has " +
+                               std::to_string(totalSamples) + " non-missing individuals, but the CSFS requires " +
+                               std::to_string(numCsfsSamples));
+    }
+    if (foldToMinorAlleles && derivedAlleles > totalSamples - derivedAlleles) {
+      throw std::runtime_error("Minor alleles has frequency > 50%. Data is supposed to be folded.");
+    }
+    for (int distinguished = 0; distinguished < 3; distinguished++) {
+      int sample = sampleHypergeometric(totalSamples - 2, derivedAlleles - distinguished, numCsfsSamples - 2);
+      if (foldToMinorAlleles && (sample + distinguished > numCsfsSamples / 2)) {
+        sample = numCsfsSamples - 2 - sample;
+      }
+      undistinguished[i][static_cast<size_t>(distinguished)] = sample;
+    }
+  }
+  return undistinguished;
+}
+
+} // namespace fsmc_host

@@ -1,0 +1,877 @@
+// hmm.cpp -- host orchestration of the pairwise decode (counterpart of the reference's HMM.cpp).
+// Everything numerical on the hot path happens in libfastsmc_hip.so; this file prepares its constant
+// inputs exactly like HMM::HMM does, turns the reference's pair/batch bookkeeping into a GPU work
+// list, and writes results in the reference's formats and order.
+#include "hmm.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <iomanip>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+#include "util.hpp"
+
+namespace fsmc_host
+{
+
+// ------------------------------------------------------------------ HmmUtils counterparts
+
+float roundMorgans(const float value, const int precision, const float min)
+{
+  if (value <= min) {
+    return min;
+  }
+  const float correction = 10.f - static_cast<float>(precision);
+  const float L10 = std::max<float>(0.f, floorf(log10f(value)) + correction);
+  const float factor = powf(10.f, 10.f - L10);
+  return roundf(value * factor) / factor;
+}
+
+int roundPhysical(const int value, const int precision)
+{
+  if (value <= 1) {
+    return 1;
+  }
+  const int L10 = std::max<int>(0, static_cast<int>(floor(log10(value))) - precision);
+  const int factor = static_cast<int>(pow(10, L10));
+  return static_cast<int>(round(value / static_cast<double>(factor))) * factor;
+}
+
+unsigned getFromPosition(const std::vector<float>& gen, unsigned from, const float cmDist)
+{
+  float cum = 0.f;
+  while (cum < cmDist && from > 0u) {
+    from--;
+    cum += (gen[from + 1u] - gen[from]) * 100.f;
+  }
+  return from;
+}
+
+unsigned getToPosition(const std::vector<float>& gen, unsigned to, const float cmDist)
+{
+  float cum = 0.f;
+  while (cum < cmDist && to + 1u < gen.size()) {
+    to++;
+    cum += (gen[to] - gen[to - 1u]) * 100.f;
+  }
+  return std::min<unsigned>(to + 1u, static_cast<unsigned>(gen.size()));
+}
+
+std::pair<unsigned long, unsigned long> hapToDipId(unsigned long hapId)
+{
+  return {hapId / 2ul, 1ul + (hapId % 2ul)};
+}
+
+unsigned long dipToHapId(unsigned long ind, unsigned long hap)
+{
+  return 2ul * ind + hap - 1ul;
+}
+
+std::string indPlusHapToCombinedId(const std::string& indId, unsigned long hap)
+{
+  if (indId.empty() || !(hap == 1ul || hap == 2ul)) {
+    throw std::runtime_error("Expected an individual ID and either 1 or 2, but got " + indId + " and " +
+                             std::to_string(hap) + "\n");
+  }
+  return indId + "#" + std::to_string(hap);
+}
+
+std::pair<std::string, unsigned long> combinedIdToIndPlusHap(const std::string& id)
+{
+  const size_t n = id.length();
+  if (n < 3 || !(id.compare(n - 2, 2, "#1") == 0 || id.compare(n - 2, 2, "#2") == 0)) {
+    throw std::runtime_error("Expected combined ID in form <id>#1 OR <id>#2, but got " + id + "\n");
+  }
+  return {id.substr(0, n - 2), id.back() == '1' ? 1ul : 2ul};
+}
+
+unsigned long getIndIdxFromIdString(const std::vector<std::string>& ids, const std::string& id)
+{
+  auto it = std::find(ids.begin(), ids.end(), id);
+  if (it == ids.end()) {
+    throw std::runtime_error("The ID string " + id + " is not in the list of IDs\n");
+  }
+  return static_cast<unsigned long>(std::distance(ids.begin(), it));
+}
+
+// ------------------------------------------------------------------ return structs
+
+void DecodePairsReturnStruct::initialise(const std::vector<unsigned long>& hapsA, const std::vector<unsigned long>&,
+                                         long sites, long states, bool fullPosteriors, bool sumOfPost,
+                                         bool perPairMeans, bool perPairMaps)
+{
+  numWritten = 0;
+  numPairs = static_cast<long>(hapsA.size());
+  numSites = sites;
+  numStates = states;
+  storeFullPosteriors = fullPosteriors;
+  storeSumOfPosteriors = sumOfPost;
+  storePerPairPosteriorMeans = perPairMeans;
+  storePerPairMAPs = perPairMaps;
+  perPairIndices.assign(static_cast<size_t>(numPairs), {});
+  perPairPosteriors.clear();
+  sumOfPosteriors.clear();
+  perPairPosteriorMeans.clear();
+  perPairMAPs.clear();
+  minPosteriorMeans.clear();
+  argminPosteriorMeans.clear();
+  minMAPs.clear();
+  argminMAPs.clear();
+  if (fullPosteriors) {
+    perPairPosteriors.assign(static_cast<size_t>(numPairs), std::vector<float>(static_cast<size_t>(states * sites)));
+  }
+  if (sumOfPost) {
+    sumOfPosteriors.assign(static_cast<size_t>(states * sites), 0.f);
+  }
+  if (perPairMeans) {
+    perPairPosteriorMeans.assign(static_cast<size_t>(numPairs * sites), 0.f);
+    minPosteriorMeans.assign(static_cast<size_t>(sites), 0.f);
+    argminPosteriorMeans.assign(static_cast<size_t>(sites), 0);
+  }
+  if (perPairMaps) {
+    perPairMAPs.assign(static_cast<size_t>(numPairs * sites), 0);
+    minMAPs.assign(static_cast<size_t>(sites), 0);
+    argminMAPs.assign(static_cast<size_t>(sites), 0);
+  }
+}
+
+void DecodePairsReturnStruct::finaliseCalculations()
+{
+  // column-wise min / first argmin (DecodePairsReturnStruct.hpp:105-118)
+  if (!perPairPosteriorMeans.empty()) {
+    for (long s = 0; s < numSites; ++s) {
+      long arg = 0;
+      float best = perPairPosteriorMeans[static_cast<size_t>(s)];
+      for (long p = 1; p < numPairs; ++p) {
+        const float v = perPairPosteriorMeans[static_cast<size_t>(p * numSites + s)];
+        if (v < best) {
+          best = v;
+          arg = p;
+        }
+      }
+      minPosteriorMeans[static_cast<size_t>(s)] = best;
+      argminPosteriorMeans[static_cast<size_t>(s)] = static_cast<int>(arg);
+    }
+  }
+  if (!perPairMAPs.empty()) {
+    for (long s = 0; s < numSites; ++s) {
+      long arg = 0;
+      int best = perPairMAPs[static_cast<size_t>(s)];
+      for (long p = 1; p < numPairs; ++p) {
+        const int v = perPairMAPs[static_cast<size_t>(p * numSites + s)];
+        if (v < best) {
+          best = v;
+          arg = p;
+        }
+      }
+      minMAPs[static_cast<size_t>(s)] = best;
+      argminMAPs[static_cast<size_t>(s)] = static_cast<int>(arg);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ construction
+
+namespace
+{
+void check(fsmc_ctx* ctx, int rc, const char* what)
+{
+  if (rc != FSMC_OK) {
+    throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + fsmc_last_error(ctx));
+  }
+}
+} // namespace
+
+HMM::HMM(Data data, const DecodingParams& params, int scalingSkip)
+    : mData(std::move(data)), mDq(params.decodingQuantFile), mParams(params)
+{
+  init(scalingSkip);
+}
+
+HMM::HMM(Data data, DecodingQuantities dq, const DecodingParams& params, int scalingSkip)
+    : mData(std::move(data)), mDq(std::move(dq)), mParams(params)
+{
+  init(scalingSkip);
+}
+
+void HMM::init(int scalingSkip)
+{
+  if (mParams.hashing && !mParams.FastSMC) {
+    throw std::runtime_error("Identification only is not yet supported: cannot have hashing==true and "
+                             "FastSMC==false.");
+  }
+  if (scalingSkip != 1) {
+    // every caller in the reference uses 1 (HMM.hpp:172, pybind.cpp:219); the GPU path rescales every site
+    throw std::runtime_error("scalingSkip != 1 is not supported");
+  }
+  if (mParams.decodingSequence) {
+    throw std::runtime_error("sequence mode (two-step transition with homozygous emissions) is outside this "
+                             "build's hot-path scope; use array mode");
+  }
+  if (mParams.noBatches) {
+    // the reference's noBatches runs its scalar debugging path; here every decode is batched on the GPU
+    mParams.noBatches = false;
+  }
+  mBatchSize = mParams.batchSize;
+  if (mBatchSize <= 0) {
+    throw std::runtime_error("batchSize must be positive");
+  }
+  mFromBatch.assign(static_cast<size_t>(mBatchSize), 0u);
+  mToBatch.assign(static_cast<size_t>(mBatchSize), static_cast<unsigned>(mData.sites));
+  prepareModel();
+  mReturn.sites = mData.sites;
+  mReturn.states = mDq.states;
+  mReturn.siteWasFlippedDuringFolding = mData.siteWasFlippedDuringFolding;
+  resetDecoding();
+}
+
+HMM::~HMM()
+{
+  if (mIbdFile) {
+    gzclose(mIbdFile);
+  }
+  if (mModel) {
+    fsmc_model_destroy(mModel);
+  }
+  if (mCtx) {
+    fsmc_ctx_destroy(mCtx);
+  }
+}
+
+void HMM::prepareEmissions()
+{
+  // HMM.cpp:159-256, array mode (decodingSequence == false)
+  const int S = mData.sites;
+  const int K = static_cast<int>(mDq.states);
+  const auto undist = mData.calculateUndistinguishedCounts(mDq.CSFSSamples);
+  mUseCSFS.assign(static_cast<size_t>(S), false);
+  if (mParams.skipCSFSdistance < std::numeric_limits<float>::infinity()) {
+    mUseCSFS[0] = true;
+    float lastGenCSFSwasUsed = 0.f;
+    for (int pos = 1; pos < S; pos++) {
+      if (mData.geneticPositions[pos] - lastGenCSFSwasUsed >= mParams.skipCSFSdistance) {
+        mUseCSFS[pos] = true;
+        lastGenCSFSwasUsed = mData.geneticPositions[pos];
+      }
+    }
+  }
+  mPrep.e1.assign(static_cast<size_t>(S) * K, 0.f);
+  mPrep.e0m1.assign(static_cast<size_t>(S) * K, 0.f);
+  mPrep.e2m0.assign(static_cast<size_t>(S) * K, 0.f);
+  auto csfsRow = [&](const std::vector<std::vector<std::vector<float>>>& map, int u, int d) -> const float* {
+    if (u < 0 || static_cast<size_t>(u) >= map.size() || map[u].size() <= static_cast<size_t>(d) ||
+        map[u][d].size() != static_cast<size_t>(K)) {
+      throw std::runtime_error("decoding quantities lack the CSFS row for undistinguished count " +
+                               std::to_string(u));
+    }
+    return map[u][d].data();
+  };
+  for (int pos = 0; pos < S; pos++) {
+    float* e1 = &mPrep.e1[static_cast<size_t>(pos) * K];
+    float* e0m1 = &mPrep.e0m1[static_cast<size_t>(pos) * K];
+    float* e2m0 = &mPrep.e2m0[static_cast<size_t>(pos) * K];
+    if (mUseCSFS[pos]) {
+      const int u0 = undist[pos][0], u1 = undist[pos][1], u2 = undist[pos][2];
+      if (mParams.foldData) {
+        const auto& map = mDq.foldedAscertainedCSFSmap;
+        const float* r1 = u1 >= 0 ? csfsRow(map, u1, 1) : nullptr;
+        const float* r0 = csfsRow(map, u0, 0);
+        const float* r2 = u2 >= 0 ? csfsRow(map, u2, 0) : nullptr;
+        for (int k = 0; k < K; k++) {
+          e1[k] = r1 ? r1[k] : 0.f;
+          e0m1[k] = r0[k] - e1[k];
+          e2m0[k] = r2 ? (r2[k] - r0[k]) : (0 - r0[k]);
+        }
+      } else {
+        const auto& map = mDq.ascertainedCSFSmap;
+        const float* r1 = u1 >= 0 ? csfsRow(map, u1, 1) : nullptr;
+        const float* r0 = u0 >= 0 ? csfsRow(map, u0, 0) : nullptr;
+        const float* r2 = nullptr;
+        if (u2 >= 0) {
+          // monomorphic derived folds to CSFS[0][0] (HMM.cpp:226-232)
+          r2 = (u2 == mDq.CSFSSamples - 2) ? csfsRow(map, 0, 0) : csfsRow(map, u2, 2);
+        }
+        for (int k = 0; k < K; k++) {
+          e1[k] = r1 ? r1[k] : 0.f;
+          const float e0 = r0 ? r0[k] : 0.f;
+          e0m1[k] = e0 - e1[k];
+          e2m0[k] = r2 ? (r2[k] - e0) : (0 - e0);
+        }
+      }
+    } else {
+      if (mDq.compressedEmissionTable.size() != 2) {
+        throw std::runtime_error("decoding quantities lack the CompressedAscertainedEmission table");
+      }
+      const float* c0 = mDq.compressedEmissionTable[0].data();
+      const float* c1 = mDq.compressedEmissionTable[1].data();
+      for (int k = 0; k < K; k++) {
+        e1[k] = c1[k];
+        e0m1[k] = c0[k] - c1[k];
+        e2m0[k] = 0.f;
+      }
+    }
+  }
+}
+
+void HMM::prepareModel()
+{
+  const int S = mData.sites;
+  const int K = static_cast<int>(mDq.states);
+  if (S < 1) {
+    throw std::runtime_error("no sites to decode");
+  }
+  if (static_cast<int>(mDq.initialStateProb.size()) != K || static_cast<int>(mDq.expectedTimes.size()) != K ||
+      static_cast<int>(mDq.discretization.size()) != K + 1 || static_cast<int>(mDq.columnRatios.size()) != K) {
+    throw std::runtime_error("decoding quantities are incomplete (initialStateProb / expectedTimes / "
+                             "discretization / columnRatios)");
+  }
+  mPrep.K = K;
+  mPrep.S = S;
+  mPrep.pi = mDq.initialStateProb;
+  mPrep.colRatios = mDq.columnRatios;
+  mPrep.expTimes = mDq.expectedTimes;
+  prepareEmissions();
+
+  // Transition-table row per site step: key = roundMorgans(gen[p] - gen[p-1]) in fp32, exact-match lookup
+  // (HMM.cpp:755, 795-797, 909, 951-954).  Only the rows this data set touches are kept.
+  const int precision = 2;
+  const float minGenetic = 1e-10f;
+  mPrep.stepRow.assign(static_cast<size_t>(S), 0);
+  std::map<uint32_t, int> rowOfKey;
+  std::vector<float> keys;
+  for (int p = 1; p < S; ++p) {
+    const float key = roundMorgans(mData.geneticPositions[p] - mData.geneticPositions[p - 1], precision, minGenetic);
+    auto it = rowOfKey.find(floatBits(key));
+    if (it == rowOfKey.end()) {
+      it = rowOfKey.emplace(floatBits(key), static_cast<int>(keys.size())).first;
+      keys.push_back(key);
+    }
+    mPrep.stepRow[p] = it->second;
+  }
+  if (keys.empty()) {
+    keys.push_back(minGenetic);
+  }
+  mPrep.nRows = static_cast<int>(keys.size());
+  auto gather = [&](const KeyedTable& t, const char* name) {
+    std::vector<float> out(keys.size() * static_cast<size_t>(K));
+    for (size_t r = 0; r < keys.size(); ++r) {
+      const int src = t.find(keys[r]);
+      if (src < 0) { // the reference throws std::out_of_range from unordered_map::at
+        std::ostringstream os;
+        os << std::setprecision(9) << "no " << name << " entry for genetic distance " << keys[r];
+        throw std::out_of_range(os.str());
+      }
+      std::copy(t.row(src, K), t.row(src, K) + K, out.begin() + r * K);
+    }
+    return out;
+  };
+  mPrep.D = gather(mDq.Dvectors, "Dvectors");
+  mPrep.B = gather(mDq.Bvectors, "Bvectors");
+  mPrep.U = gather(mDq.Uvectors, "Uvectors");
+  mPrep.RR = gather(mDq.rowRatioVectors, "RowRatios");
+
+  // HMM::getStateThreshold (HMM.cpp:504-513) and the probability threshold (HMM.cpp:96-99)
+  unsigned st = 0;
+  while (st < mDq.states && mDq.discretization[st] < static_cast<float>(mParams.time)) {
+    st++;
+  }
+  mPrep.stateThreshold = st;
+  float pthr = 0.f;
+  for (unsigned i = 0; i < st; i++) {
+    pthr += mDq.initialStateProb.at(i);
+  }
+  mPrep.probabilityThreshold = pthr;
+  mPrep.ageThreshold = mParams.noConditionalAgeEstimates ? mDq.states : st;
+  mExpectedCoalTimes = mDq.expectedTimes;
+}
+
+void HMM::resetDecoding()
+{
+  const size_t n = static_cast<size_t>(mData.sites) * mDq.states;
+  mReturn.sumOverPairs.assign(n, 0.f);
+  if (mParams.doMajorMinorPosteriorSums) {
+    mReturn.sumOverPairs00.assign(n, 0.f);
+    mReturn.sumOverPairs01.assign(n, 0.f);
+    mReturn.sumOverPairs11.assign(n, 0.f);
+  }
+}
+
+void HMM::ensureEngine()
+{
+  if (!mCtx) {
+    int rc = fsmc_ctx_create(mParams.gpuDevice, nullptr, &mCtx);
+    if (rc != FSMC_OK) {
+      mCtx = nullptr;
+      throw std::runtime_error(std::string("cannot open the MI355X decode engine: ") + fsmc_last_error(nullptr));
+    }
+  }
+  if (!mModel) {
+    fsmc_model_desc d{};
+    d.K = mPrep.K;
+    d.S = mPrep.S;
+    d.pi = mPrep.pi.data();
+    d.col_ratios = mPrep.colRatios.data();
+    d.exp_times = mPrep.expTimes.data();
+    d.n_rows = mPrep.nRows;
+    d.D = mPrep.D.data();
+    d.B = mPrep.B.data();
+    d.U = mPrep.U.data();
+    d.RR = mPrep.RR.data();
+    d.step_row = mPrep.stepRow.data();
+    d.e1 = mPrep.e1.data();
+    d.e0m1 = mPrep.e0m1.data();
+    d.e2m0 = mPrep.e2m0.data();
+    d.state_threshold = mPrep.stateThreshold;
+    d.age_threshold = mPrep.ageThreshold;
+    d.probability_threshold = mPrep.probabilityThreshold;
+    check(mCtx, fsmc_model_create(mCtx, &d, &mModel), "fsmc_model_create");
+  }
+  if (!mHapsUploaded) {
+    check(mCtx,
+          fsmc_haps_upload(mCtx, mData.bits.data(), static_cast<uint32_t>(mData.numHapRows()),
+                           static_cast<uint32_t>(mData.sites)),
+          "fsmc_haps_upload");
+    mHapsUploaded = true;
+  }
+}
+
+// ------------------------------------------------------------------ queueing (HMM.cpp:283-636)
+
+PairObservations HMM::makePairObs(int_least8_t iHap, unsigned ind1, int_least8_t jHap, unsigned ind2) const
+{
+  PairObservations ret;
+  ret.iHap = iHap;
+  ret.jHap = jHap;
+  ret.iInd = ind1;
+  ret.jInd = ind2;
+  const bool wholeSequence = !(mParams.FastSMC && mParams.hashing);
+  if (wholeSequence) { // HMM.cpp:139-142; in hashing mode bits are made per batch window
+    const size_t ra = dipToHapId(ind1, static_cast<unsigned long>(iHap));
+    const size_t rb = dipToHapId(ind2, static_cast<unsigned long>(jHap));
+    const size_t S = static_cast<size_t>(mData.sites);
+    ret.obsBits.resize(S);
+    ret.homMinorBits.resize(S);
+    for (size_t s = 0; s < S; ++s) {
+      const bool a = mData.genotype(ra, s), b = mData.genotype(rb, s);
+      ret.obsBits[s] = a ^ b;
+      ret.homMinorBits[s] = a & b;
+    }
+  }
+  return ret;
+}
+
+void HMM::queuePair(unsigned hapRowA, unsigned hapRowB)
+{
+  if (hapRowA >= mData.numHapRows() || hapRowB >= mData.numHapRows()) {
+    throw std::runtime_error("haplotype index out of range");
+  }
+  mPairs.push_back(fsmc_pair{hapRowA, hapRowB});
+  if (mPairs.size() - mBatchBegin == static_cast<size_t>(mBatchSize)) {
+    closeBatch(false);
+    if (mPairs.size() >= mFlushThreshold) {
+      flush();
+    }
+  }
+}
+
+void HMM::closeBatch(bool last)
+{
+  // addToBatch / runLastBatch (HMM.cpp:555-636): the batch's decode window is the union of its pairs'
+  // windows padded by 0.5 cM; in hashing mode every pair is scanned over the un-padded union
+  // (HMM.cpp:1199-1204).  The reference pads the last batch to a multiple of its SIMD width with
+  // copies of the last pair; lanes are independent, so no padding is needed here.
+  const size_t n = mPairs.size() - mBatchBegin;
+  if (n == 0) {
+    return;
+  }
+  const size_t slots = last ? n : static_cast<size_t>(mBatchSize);
+  const unsigned startBatch = *std::min_element(mFromBatch.begin(), mFromBatch.begin() + slots);
+  const unsigned endBatch = *std::max_element(mToBatch.begin(), mToBatch.begin() + slots);
+  const unsigned from = getFromPosition(mData.geneticPositions, startBatch);
+  const unsigned to = getToPosition(mData.geneticPositions, endBatch);
+  unsigned scanFrom = 0, scanTo = static_cast<unsigned>(mData.sites);
+  if (mParams.FastSMC && mParams.hashing) {
+    scanFrom = startBatch;
+    scanTo = endBatch;
+  }
+  if (scanTo <= scanFrom) {
+    // the reference's scan loop would be empty: nothing is ever output for this batch
+    mPairs.resize(mBatchBegin);
+    return;
+  }
+  for (size_t off = 0; off < n; off += 64) {
+    fsmc_group g{};
+    g.first_pair = static_cast<uint32_t>(mBatchBegin + off);
+    g.n_pairs = static_cast<uint32_t>(std::min<size_t>(64, n - off));
+    g.from = from;
+    g.to = to;
+    g.scan_from = scanFrom;
+    g.scan_to = scanTo;
+    mGroups.push_back(g);
+  }
+  mBatchBegin = mPairs.size();
+}
+
+void HMM::flush()
+{
+  if (mGroups.empty()) {
+    return;
+  }
+  ensureEngine();
+  const size_t nPairs = mBatchBegin; // pairs covered by closed batches
+  check(mCtx, fsmc_worklist_upload(mCtx, mPairs.data(), nPairs, mGroups.data(), mGroups.size()),
+        "fsmc_worklist_upload");
+
+  if (mParams.FastSMC) {
+    uint32_t flags = 0;
+    if (mParams.doPerPairPosteriorMean) flags |= FSMC_WANT_MEAN;
+    if (mParams.doPerPairMAP) flags |= FSMC_WANT_MAP;
+    check(mCtx, fsmc_decode_ibd_launch(mCtx, mModel, flags), "fsmc_decode_ibd_launch");
+    std::vector<fsmc_ibd_record> recs(std::max<size_t>(1024, 4 * nPairs));
+    size_t n = 0;
+    int rc = fsmc_decode_ibd_fetch(mCtx, recs.data(), recs.size(), &n);
+    if (rc == FSMC_EOVERFLOW) {
+      recs.resize(n);
+      rc = fsmc_decode_ibd_fetch(mCtx, recs.data(), recs.size(), &n);
+    }
+    check(mCtx, rc, "fsmc_decode_ibd_fetch");
+    for (size_t i = 0; i < n; ++i) {
+      writeIbd(mPairs[recs[i].pair], recs[i]);
+    }
+  }
+  if (mParams.doPosteriorSums || mParams.doMajorMinorPosteriorSums) {
+    const bool mm = mParams.doMajorMinorPosteriorSums;
+    check(mCtx,
+          fsmc_decode_sums(mCtx, mModel, mParams.doPosteriorSums ? mReturn.sumOverPairs.data() : nullptr,
+                           mm ? mReturn.sumOverPairs00.data() : nullptr, mm ? mReturn.sumOverPairs01.data() : nullptr,
+                           mm ? mReturn.sumOverPairs11.data() : nullptr),
+          "fsmc_decode_sums");
+  }
+  if (!mParams.FastSMC && (mStoreMean || mStoreMap || mStorePosterior || mStoreSumOfPosterior)) {
+    // writePerPairOutput (HMM.cpp:1360-1458)
+    const size_t S = static_cast<size_t>(mData.sites);
+    const size_t K = mDq.states;
+    auto& R = mPairsReturn;
+    const size_t base = R.numWritten;
+    if (base + nPairs > static_cast<size_t>(R.numPairs)) {
+      throw std::runtime_error("more pairs decoded than the return structure was initialised for");
+    }
+    const bool wantMean = mStoreMean || mStorePosterior || mStoreSumOfPosterior;
+    std::vector<float> mean(wantMean ? nPairs * S : 0);
+    std::vector<int32_t> map(mStoreMap || mStoreMean ? nPairs * S : 0);
+    check(mCtx,
+          fsmc_decode_per_pair(mCtx, mModel, mExpectedCoalTimes.data(), mean.empty() ? nullptr : mean.data(),
+                               map.empty() ? nullptr : map.data()),
+          "fsmc_decode_per_pair");
+    if (mStorePosterior || mStoreSumOfPosterior) {
+      // full posteriors (times expected coalescence time, HMM.cpp:1382-1388) come from the posterior dump
+      std::vector<float> dump(static_cast<size_t>(64) * K * S * mGroups.size());
+      check(mCtx, fsmc_decode_posteriors(mCtx, mModel, dump.data(), dump.size()), "fsmc_decode_posteriors");
+      for (size_t g = 0; g < mGroups.size(); ++g) {
+        const float* gp = dump.data() + g * 64 * K * S;
+        for (uint32_t v = 0; v < mGroups[g].n_pairs; ++v) {
+          const size_t pairIdx = mGroups[g].first_pair + v;
+          for (size_t pos = 0; pos < S; ++pos) {
+            for (size_t k = 0; k < K; ++k) {
+              const float postValue = gp[(pos * K + k) * 64 + v] * mExpectedCoalTimes[k];
+              if (mStorePosterior) {
+                R.perPairPosteriors[base + pairIdx][k * S + pos] = postValue;
+              }
+              if (mStoreSumOfPosterior) {
+                R.sumOfPosteriors[k * S + pos] += postValue;
+              }
+            }
+          }
+        }
+      }
+    }
+    for (size_t i = 0; i < nPairs; ++i) {
+      const auto [indA, hapA] = hapToDipId(mPairs[i].hap_a);
+      const auto [indB, hapB] = hapToDipId(mPairs[i].hap_b);
+      R.perPairIndices.at(base + i) =
+          std::make_tuple(static_cast<unsigned long>(mPairs[i].hap_a), indPlusHapToCombinedId(mData.IIDList.at(indA), hapA),
+                          static_cast<unsigned long>(mPairs[i].hap_b), indPlusHapToCombinedId(mData.IIDList.at(indB), hapB));
+      if (mStoreMean) {
+        std::copy(mean.begin() + i * S, mean.begin() + (i + 1) * S, R.perPairPosteriorMeans.begin() + (base + i) * S);
+        // the reference stores the MAP rows under the posterior-mean flag (HMM.cpp:1447-1449)
+        if (!R.perPairMAPs.empty() && !map.empty()) {
+          std::copy(map.begin() + i * S, map.begin() + (i + 1) * S, R.perPairMAPs.begin() + (base + i) * S);
+        }
+      }
+    }
+    R.numWritten += nPairs;
+  }
+
+  // keep any pairs of a still-open batch
+  std::vector<fsmc_pair> rest(mPairs.begin() + static_cast<long>(mBatchBegin), mPairs.end());
+  mPairs.swap(rest);
+  mGroups.clear();
+  mBatchBegin = 0;
+}
+
+void HMM::openIbdFile(int jobs, int jobInd)
+{
+  if (mIbdFile) {
+    gzclose(mIbdFile);
+    mIbdFile = nullptr;
+  }
+  const std::string base = mParams.outFileRoot + "." + std::to_string(jobInd) + "." + std::to_string(jobs);
+  if (!mParams.BIN_OUT) {
+    mIbdFile = gzopen((base + ".FastSMC.ibd.gz").c_str(), "w");
+  } else {
+    mIbdFile = gzopen((base + ".FastSMC.bibd.gz").c_str(), "wb");
+  }
+  if (!mIbdFile) {
+    throw std::runtime_error("cannot open IBD output file with prefix " + base);
+  }
+  if (mParams.BIN_OUT) {
+    writeBinaryHeader();
+  }
+}
+
+void HMM::decodeAll(int jobs, int jobInd)
+{
+  resetDecoding();
+  const unsigned long long N = mData.numIndividuals();
+  if (mParams.FastSMC) {
+    openIbdFile(jobs, jobInd);
+    if (mParams.hashing) {
+      return; // pairs arrive through decodeFromHashing
+    }
+  }
+  // pair range of this job (HMM.cpp:310-321)
+  const unsigned long long totPairs = mParams.withinOnly ? N : 2 * N * N - N;
+  const unsigned long long pairsStart = totPairs * static_cast<unsigned long long>(jobInd - 1) / jobs;
+  const unsigned long long pairsEnd = totPairs * static_cast<unsigned long long>(jobInd) / jobs;
+  unsigned long long pairs = 0;
+  for (unsigned i = 0; i < N; i++) {
+    if (!mParams.withinOnly) {
+      for (unsigned j = 0; j < i; j++) {
+        for (int iHap = 1; iHap <= 2; iHap++) {
+          for (int jHap = 1; jHap <= 2; jHap++) {
+            if (pairsStart <= pairs && pairs < pairsEnd) {
+              // makePairObs(jHap, j, iHap, i): the lower-numbered individual is the record's first id
+              queuePair(static_cast<unsigned>(dipToHapId(j, jHap)), static_cast<unsigned>(dipToHapId(i, iHap)));
+            }
+            pairs++;
+          }
+        }
+      }
+    }
+    if (pairsStart <= pairs && pairs < pairsEnd) {
+      queuePair(static_cast<unsigned>(dipToHapId(i, 1)), static_cast<unsigned>(dipToHapId(i, 2)));
+    }
+    pairs++;
+  }
+  finishDecoding();
+}
+
+void HMM::decodePairs(const std::vector<unsigned>& A, const std::vector<unsigned>& B)
+{
+  if (A.size() != B.size()) {
+    throw std::runtime_error("vector of A indicies must be the same size as vector of B indicies");
+  }
+  for (size_t i = 0; i < A.size(); ++i) {
+    decodePair(A[i], B[i]);
+  }
+}
+
+void HMM::decodePair(const unsigned i, const unsigned j)
+{
+  if (i >= mData.numIndividuals() || j >= mData.numIndividuals()) {
+    throw std::runtime_error("individual index out of range");
+  }
+  if (i != j) {
+    for (int iHap = 1; iHap <= 2; iHap++) {
+      for (int jHap = 1; jHap <= 2; jHap++) {
+        queuePair(static_cast<unsigned>(dipToHapId(i, iHap)), static_cast<unsigned>(dipToHapId(j, jHap)));
+      }
+    }
+  } else {
+    queuePair(static_cast<unsigned>(dipToHapId(i, 1)), static_cast<unsigned>(dipToHapId(i, 2)));
+  }
+}
+
+void HMM::decodeHapPair(const unsigned long i, const unsigned long j)
+{
+  queuePair(static_cast<unsigned>(i), static_cast<unsigned>(j));
+}
+
+void HMM::decodeHapPairs(const std::vector<unsigned long>& A, const std::vector<unsigned long>& B)
+{
+  if (A.size() != B.size()) {
+    throw std::runtime_error("vector of A indices must be the same size as vector of B indices");
+  }
+  for (size_t i = 0; i < A.size(); ++i) {
+    decodeHapPair(A[i], B[i]);
+  }
+}
+
+void HMM::decodeFromHashing(const unsigned hapA, const unsigned hapB, const unsigned fromPos, const unsigned toPos)
+{
+  if (hapA / 2 >= mData.numIndividuals() || hapB / 2 >= mData.numIndividuals() ||
+      fromPos >= static_cast<unsigned>(mData.sites) || toPos >= static_cast<unsigned>(mData.sites)) {
+    throw std::runtime_error("decodeFromHashing: index out of range");
+  }
+  const size_t slot = mHashingCount % static_cast<unsigned long>(mBatchSize);
+  mFromBatch[slot] = fromPos;
+  mToBatch[slot] = toPos;
+  mHashingCount++;
+  queuePair(hapA, hapB); // hap = id % 2 == 0 ? 1 : 2, ind = id / 2 (HMM.cpp:483-486): the row itself
+}
+
+void HMM::finishDecoding()
+{
+  closeBatch(true);
+  flush();
+  if (!(mParams.FastSMC && mParams.hashing)) {
+    std::fill(mFromBatch.begin(), mFromBatch.end(), 0u);
+    std::fill(mToBatch.begin(), mToBatch.end(), static_cast<unsigned>(mData.sites));
+  }
+}
+
+void HMM::finishFromHashing()
+{
+  closeBatch(true);
+  flush();
+  closeIBDFile();
+}
+
+void HMM::closeIBDFile()
+{
+  if (mIbdFile) {
+    gzclose(mIbdFile);
+    mIbdFile = nullptr;
+  }
+}
+
+// ------------------------------------------------------------------ output (HMM.cpp:1110-1177, 383-401)
+
+std::string HMM::formatIbdRecord(const fsmc_pair& pr, const fsmc_ibd_record& r) const
+{
+  const auto [iInd, iHap] = hapToDipId(pr.hap_a);
+  const auto [jInd, jHap] = hapToDipId(pr.hap_b);
+  std::stringstream record;
+  record << std::setprecision(std::numeric_limits<float>::digits10 + 1);
+  record << mData.FamIDList[iInd] << '\t' << mData.IIDList[iInd] << '\t' << static_cast<int>(iHap) << '\t'
+         << mData.FamIDList[jInd] << '\t' << mData.IIDList[jInd] << '\t' << static_cast<int>(jHap) << '\t'
+         << mData.chrNumber;
+  record << '\t' << mData.physicalPositions[r.start] << '\t' << mData.physicalPositions[r.end];
+  if (mParams.outputIbdSegmentLength) {
+    const float length_cM = 100.f * (mData.geneticPositions[r.end] - mData.geneticPositions[r.start]);
+    record << '\t' << length_cM;
+  }
+  const double ibd_score = r.prob / static_cast<double>(static_cast<unsigned>(r.end - r.start) + 1u);
+  record << '\t' << ibd_score;
+  if (mParams.doPerPairPosteriorMean) {
+    record << '\t' << r.post_mean;
+  }
+  if (mParams.doPerPairMAP) {
+    record << '\t' << r.map;
+  }
+  record << '\n';
+  return record.str();
+}
+
+void HMM::writeIbd(const fsmc_pair& pr, const fsmc_ibd_record& r)
+{
+  mSegmentsDetected++;
+  if (mKeepRecords) {
+    mKeptRecords.push_back(r);
+    mKeptPairs.push_back(pr);
+  }
+  if (!mIbdFile) {
+    return;
+  }
+  if (!mParams.BIN_OUT) {
+    const std::string s = formatIbdRecord(pr, r);
+    gzwrite(mIbdFile, s.c_str(), static_cast<unsigned>(s.size()));
+    return;
+  }
+  const auto [iInd, iHap] = hapToDipId(pr.hap_a);
+  const auto [jInd, jHap] = hapToDipId(pr.hap_b);
+  const unsigned int ind[2] = {static_cast<unsigned>(iInd), static_cast<unsigned>(jInd)};
+  const std::uint_least8_t hap[2] = {static_cast<std::uint_least8_t>(iHap), static_cast<std::uint_least8_t>(jHap)};
+  const int pos[2] = {mData.physicalPositions[r.start], mData.physicalPositions[r.end]};
+  const float ibd_score =
+      static_cast<float>(r.prob / static_cast<double>(static_cast<unsigned>(r.end - r.start) + 1u));
+  gzwrite(mIbdFile, &ind[0], sizeof(unsigned int));
+  gzwrite(mIbdFile, &hap[0], sizeof(std::uint_least8_t));
+  gzwrite(mIbdFile, &ind[1], sizeof(unsigned int));
+  gzwrite(mIbdFile, &hap[1], sizeof(std::uint_least8_t));
+  gzwrite(mIbdFile, &pos[0], sizeof(int));
+  gzwrite(mIbdFile, &pos[1], sizeof(int));
+  if (mParams.outputIbdSegmentLength) {
+    const float length_cM = 100.f * (mData.geneticPositions[r.end] - mData.geneticPositions[r.start]);
+    gzwrite(mIbdFile, &length_cM, sizeof(float));
+  }
+  gzwrite(mIbdFile, &ibd_score, sizeof(float));
+  if (mParams.doPerPairPosteriorMean) {
+    gzwrite(mIbdFile, &r.post_mean, sizeof(float));
+  }
+  if (mParams.doPerPairMAP) {
+    gzwrite(mIbdFile, &r.map, sizeof(float));
+  }
+}
+
+void HMM::writeBinaryHeader()
+{
+  gzwrite(mIbdFile, &mParams.outputIbdSegmentLength, sizeof(bool));
+  gzwrite(mIbdFile, &mParams.doPerPairPosteriorMean, sizeof(bool));
+  gzwrite(mIbdFile, &mParams.doPerPairMAP, sizeof(bool));
+  gzwrite(mIbdFile, &mData.chrNumber, sizeof(int));
+  const unsigned int nbInd = static_cast<unsigned>(mData.numIndividuals());
+  gzwrite(mIbdFile, &nbInd, sizeof(unsigned int));
+  for (unsigned i = 0; i < nbInd; i++) {
+    const unsigned lengthFamid = static_cast<unsigned>(mData.FamIDList[i].size());
+    gzwrite(mIbdFile, &lengthFamid, sizeof(unsigned int));
+    gzwrite(mIbdFile, mData.FamIDList[i].c_str(), lengthFamid);
+    const unsigned lengthIid = static_cast<unsigned>(mData.IIDList[i].size());
+    gzwrite(mIbdFile, &lengthIid, sizeof(unsigned int));
+    gzwrite(mIbdFile, mData.IIDList[i].c_str(), lengthIid);
+  }
+}
+
+// ------------------------------------------------------------------ single-pair decode
+
+std::vector<std::vector<float>> HMM::decode(const PairObservations& obs)
+{
+  return decode(obs, 0, static_cast<unsigned>(mData.sites));
+}
+
+std::vector<std::vector<float>> HMM::decode(const PairObservations& obs, unsigned from, unsigned to)
+{
+  if (!(from < to) || to > static_cast<unsigned>(mData.sites)) {
+    throw std::runtime_error("decode: need from < to <= sites");
+  }
+  if (!mGroups.empty() || !mPairs.empty()) {
+    throw std::runtime_error("decode: pairs are queued; call finishDecoding() first");
+  }
+  ensureEngine();
+  const fsmc_pair pr{static_cast<uint32_t>(dipToHapId(obs.iInd, static_cast<unsigned long>(obs.iHap))),
+                     static_cast<uint32_t>(dipToHapId(obs.jInd, static_cast<unsigned long>(obs.jHap)))};
+  const fsmc_group g{0, 1, from, to, from, to};
+  check(mCtx, fsmc_worklist_upload(mCtx, &pr, 1, &g, 1), "fsmc_worklist_upload");
+  const size_t K = mDq.states;
+  std::vector<float> dump(static_cast<size_t>(64) * K * (to - from));
+  check(mCtx, fsmc_decode_posteriors(mCtx, mModel, dump.data(), dump.size()), "fsmc_decode_posteriors");
+  std::vector<std::vector<float>> posterior(K, std::vector<float>(static_cast<size_t>(mData.sites), 0.f));
+  for (unsigned pos = from; pos < to; ++pos) {
+    for (size_t k = 0; k < K; ++k) {
+      posterior[k][pos] = dump[(static_cast<size_t>(pos - from) * K + k) * 64];
+    }
+  }
+  if (mParams.doPosteriorSums) {
+    for (size_t k = 0; k < K; k++) {
+      for (size_t pos = 0; pos < static_cast<size_t>(mData.sites); pos++) {
+        mReturn.sumOverPairs[pos * K + k] += posterior[k][pos];
+      }
+    }
+  }
+  return posterior;
+}
+
+} // namespace fsmc_host

@@ -1,0 +1,176 @@
+// hmm.hpp -- host orchestration of the pairwise decode: the counterpart of the reference's class HMM
+// (HMM.hpp / HMM.cpp).  Same public surface for the decode path (decodeAll, decodePair(s),
+// decodeHapPair(s), decodeFromHashing, finishDecoding, finishFromHashing, makePairObs, return structs);
+// different engine: pairs are queued into a work list of <= 64-pair groups and decoded on the GPU
+// through the C ABI of include/fastsmc_hip.h -- this file contains no arithmetic of the hot path.
+#pragma once
+
+#include <zlib.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../../include/fastsmc_hip.h"
+#include "data.hpp"
+#include "decoding_params.hpp"
+#include "decoding_quantities.hpp"
+
+namespace fsmc_host
+{
+
+// HMM.hpp:37-46
+struct PairObservations {
+  int_least8_t iHap = 0, jHap = 0;
+  unsigned int iInd = 0, jInd = 0;
+  std::vector<bool> obsBits;
+  std::vector<bool> homMinorBits;
+};
+
+// HMM.hpp:49-66; arrays are [sites][states] row-major (numpy (S, K))
+struct DecodingReturnValues {
+  std::vector<float> sumOverPairs, sumOverPairs00, sumOverPairs01, sumOverPairs11;
+  int sites = 0;
+  unsigned int states = 0;
+  std::vector<bool> siteWasFlippedDuringFolding;
+};
+
+// DecodePairsReturnStruct.hpp:29-124; matrices row-major
+struct DecodePairsReturnStruct {
+  std::vector<std::tuple<unsigned long, std::string, unsigned long, std::string>> perPairIndices;
+  std::vector<std::vector<float>> perPairPosteriors; // per pair [states][sites]
+  std::vector<float> sumOfPosteriors;                // [states][sites]
+  std::vector<float> perPairPosteriorMeans;          // [pairs][sites]
+  std::vector<float> minPosteriorMeans;              // [sites]
+  std::vector<int> argminPosteriorMeans;             // [sites]
+  std::vector<int> perPairMAPs;                      // [pairs][sites]
+  std::vector<int> minMAPs, argminMAPs;              // [sites]
+  long numPairs = 0, numSites = 0, numStates = 0;
+  bool storeFullPosteriors = false, storeSumOfPosteriors = false, storePerPairPosteriorMeans = false,
+       storePerPairMAPs = false;
+  size_t numWritten = 0;
+
+  void initialise(const std::vector<unsigned long>& hapsA, const std::vector<unsigned long>& hapsB, long sites,
+                  long states, bool fullPosteriors, bool sumOfPost, bool perPairMeans, bool perPairMaps);
+  void finaliseCalculations();
+};
+
+// The constant inputs of the path as the constructor leaves them (what fsmc_model_create receives).
+struct PreparedModel {
+  int K = 0, S = 0;
+  std::vector<float> pi, colRatios, expTimes;
+  std::vector<float> D, B, U, RR; // [nRows][K], only the rows this data set uses
+  int nRows = 0;
+  std::vector<int32_t> stepRow;        // [S]
+  std::vector<float> e1, e0m1, e2m0;   // [S][K]
+  unsigned stateThreshold = 0, ageThreshold = 0;
+  float probabilityThreshold = 0.f;
+};
+
+class HMM
+{
+public:
+  HMM(Data data, const DecodingParams& params, int scalingSkip = 1);
+  // same, with decoding quantities already in memory (synthetic models) instead of params.decodingQuantFile
+  HMM(Data data, DecodingQuantities dq, const DecodingParams& params, int scalingSkip = 1);
+  ~HMM();
+  HMM(const HMM&) = delete;
+  HMM& operator=(const HMM&) = delete;
+
+  void decodeAll(int jobs, int jobInd);                                          // HMM.cpp:283-381
+  void decodePair(unsigned i, unsigned j);                                       // HMM.cpp:413-440
+  void decodePairs(const std::vector<unsigned>& A, const std::vector<unsigned>& B); // HMM.cpp:403-411
+  void decodeHapPair(unsigned long i, unsigned long j);                          // HMM.cpp:442-458
+  void decodeHapPairs(const std::vector<unsigned long>& A, const std::vector<unsigned long>& B);
+  void decodeFromHashing(unsigned hapA, unsigned hapB, unsigned fromPos, unsigned toPos); // HMM.cpp:470-502
+  void finishDecoding();    // HMM.cpp:515-524
+  void finishFromHashing(); // HMM.cpp:531-552
+  void closeIBDFile();
+
+  PairObservations makePairObs(int_least8_t iHap, unsigned ind1, int_least8_t jHap, unsigned ind2) const;
+  // posterior of one pair, [states][to-from] (HMM::decode, HMM.cpp:1464-1508 -- here via the batched GPU path)
+  std::vector<std::vector<float>> decode(const PairObservations& obs);
+  std::vector<std::vector<float>> decode(const PairObservations& obs, unsigned from, unsigned to);
+
+  DecodingReturnValues& getDecodingReturnValues() { return mReturn; }
+  DecodePairsReturnStruct& getDecodePairsReturnStruct() { return mPairsReturn; }
+  const DecodingQuantities& getDecodingQuantities() const { return mDq; }
+  const Data& getData() const { return mData; }
+  const PreparedModel& getPreparedModel() const { return mPrep; }
+  const DecodingParams& getParams() const { return mParams; }
+  // number of pairs waiting for the next flush (the reference's batch buffer holds at most batchSize)
+  size_t getQueuedPairs() const { return mPairs.size(); }
+
+  void setStorePerPairPosteriorMean(bool v) { mStoreMean = v; }
+  void setStorePerPairMap(bool v) { mStoreMap = v; }
+  void setStorePerPairPosterior(bool v) { mStorePosterior = v; }
+  void setStoreSumOfPosterior(bool v) { mStoreSumOfPosterior = v; }
+  void resetDecoding(); // HMM.cpp:258-280
+
+  // keep emitted IBD records in memory as well (tests, benchmarks)
+  void setKeepIbdRecords(bool v) { mKeepRecords = v; }
+  const std::vector<fsmc_ibd_record>& getIbdRecords() const { return mKeptRecords; }
+  const std::vector<fsmc_pair>& getIbdRecordPairs() const { return mKeptPairs; }
+  unsigned long long getNumSegmentsDetected() const { return mSegmentsDetected; }
+
+  // text of one IBD record, exactly as HMM::writePairIBD formats it (HMM.cpp:1116-1144)
+  std::string formatIbdRecord(const fsmc_pair& pr, const fsmc_ibd_record& r) const;
+
+private:
+  void init(int scalingSkip);
+  void prepareEmissions(); // HMM.cpp:159-256
+  void prepareModel();
+  void ensureEngine();
+  void queuePair(unsigned hapRowA, unsigned hapRowB);
+  void closeBatch(bool last);
+  void flush();
+  void writeIbd(const fsmc_pair& pr, const fsmc_ibd_record& r);
+  void writeBinaryHeader(); // HMM.cpp:383-401
+  void openIbdFile(int jobs, int jobInd);
+
+  Data mData;
+  DecodingQuantities mDq;
+  DecodingParams mParams;
+  PreparedModel mPrep;
+  int mBatchSize = 64;
+  std::vector<bool> mUseCSFS;
+
+  // engine
+  fsmc_ctx* mCtx = nullptr;
+  fsmc_model* mModel = nullptr;
+  bool mHapsUploaded = false;
+
+  // work list under construction
+  std::vector<fsmc_pair> mPairs;
+  std::vector<fsmc_group> mGroups;
+  size_t mBatchBegin = 0; // first pair of the open batch
+  std::vector<unsigned> mFromBatch, mToBatch; // per slot of the open batch (hashing mode), HMM.cpp:491-493
+  unsigned long mHashingCount = 0;            // "cpt"
+  size_t mFlushThreshold = 1u << 20;
+
+  // outputs
+  gzFile mIbdFile = nullptr;
+  unsigned long long mSegmentsDetected = 0;
+  DecodingReturnValues mReturn;
+  DecodePairsReturnStruct mPairsReturn;
+  bool mStoreMean = false, mStoreMap = false, mStorePosterior = false, mStoreSumOfPosterior = false;
+  bool mKeepRecords = false;
+  std::vector<fsmc_ibd_record> mKeptRecords;
+  std::vector<fsmc_pair> mKeptPairs;
+  std::vector<float> mExpectedCoalTimes;
+};
+
+// helpers shared with the drivers (HmmUtils.cpp)
+float roundMorgans(float value, int precision, float min);                      // HmmUtils.cpp:65-79
+int roundPhysical(int value, int precision);                                    // HmmUtils.cpp:81-94
+unsigned getFromPosition(const std::vector<float>& gen, unsigned from, float cmDist = 0.5f); // :153-164
+unsigned getToPosition(const std::vector<float>& gen, unsigned to, float cmDist = 0.5f);     // :166-177
+std::pair<unsigned long, unsigned long> hapToDipId(unsigned long hapId);        // :179-182
+unsigned long dipToHapId(unsigned long ind, unsigned long hap);                 // :184-188
+std::string indPlusHapToCombinedId(const std::string& indId, unsigned long hap);          // :190-198
+std::pair<std::string, unsigned long> combinedIdToIndPlusHap(const std::string& combinedId); // :200-208
+unsigned long getIndIdxFromIdString(const std::vector<std::string>& ids, const std::string& id); // :210-217
+
+} // namespace fsmc_host
