@@ -26,6 +26,13 @@ namespace fsmc
 {
 
 constexpr int kWave = 64;
+
+// Read-only, wave-uniform model data is addressed through the constant address space: the compiler
+// may then use scalar (SMEM) loads into SGPRs instead of per-lane vector loads + v_readfirstlane.
+// Valid because nothing in a launch ever writes these buffers.
+typedef const float __attribute__((address_space(4))) * cfloat_p;
+typedef const int __attribute__((address_space(4))) * cint_p;
+typedef const unsigned __attribute__((address_space(4))) * cuint_p;
 constexpr int kMaxGenericK = 256; // upper bound on K for the generic (runtime-K) kernel
 
 enum Mode : int { kModeIbd = 0, kModeDump = 1, kModePerPair = 2, kModeSums = 3 };
@@ -72,9 +79,8 @@ struct KParams {
 // b: beta of site pos+1 (scaled) on entry, beta of site pos (scaled) on exit.  w: scratch.
 // e: this lane's emission row for site pos+1 (LDS).  Dr/Br/Ur/RRr: wave-uniform table rows.
 template <int KT, int KA>
-__device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], const float* __restrict__ Dr,
-                                          const float* __restrict__ Br, const float* __restrict__ Ur,
-                                          const float* __restrict__ RRr, const float4* e)
+__device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
+                                          cfloat_p Ur, cfloat_p RRr, const float4* e)
 {
   const int K4 = (K + 3) >> 2;
 #pragma unroll
@@ -110,9 +116,8 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
 // One step of the forward recursion (HMM.cpp:799-830) followed by the per-site scaling
 // (HmmUtils.cpp:102-151).  a: alpha of site pos-1 on entry, of site pos on exit.
 template <int KT, int KA>
-__device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], const float* __restrict__ Dr,
-                                           const float* __restrict__ Br, const float* __restrict__ Ur,
-                                           const float* __restrict__ cR, const float4* e)
+__device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
+                                           cfloat_p Ur, cfloat_p cR, const float4* e)
 {
   w[K - 1] = a[K - 1];
 #pragma unroll
@@ -147,8 +152,7 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
 
 // alpha at the first site of the window: pi * emission, scaled (HMM.cpp:736-747).
 template <int KT, int KA>
-__device__ __forceinline__ void alpha_init(const int K, float (&a)[KA], const float* __restrict__ pi,
-                                           const float4* e)
+__device__ __forceinline__ void alpha_init(const int K, float (&a)[KA], cfloat_p pi, const float4* e)
 {
   float sum = 0.f;
   float4 ev = {0.f, 0.f, 0.f, 0.f};
@@ -216,9 +220,9 @@ template <int KT, int KA> __device__ __forceinline__ void load_vec(const int K, 
 // Segment age estimates from the per-state posterior sums of a segment
 // (HMM::getPosteriorMean, HMM.cpp:1087-1097; HMM::getMAP, 1099-1107).
 template <int KT, int KA>
-__device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, const float (&sps)[KA],
-                                             const float* __restrict__ pi, const float* __restrict__ expT,
-                                             const bool wantMean, const bool wantMap, float& mean, float& mapv)
+__device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, const float (&sps)[KA], cfloat_p pi,
+                                             cfloat_p expT, const bool wantMean, const bool wantMap, float& mean,
+                                             float& mapv)
 {
   mean = 0.f;
   mapv = 0.f;
@@ -263,6 +267,9 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   __shared__ float4 emisLds[2][3 * K4A];
 
   const int lane = threadIdx.x;
+  const cfloat_p tD = (cfloat_p)p.D, tB = (cfloat_p)p.B, tU = (cfloat_p)p.U, tRR = (cfloat_p)p.RR;
+  const cfloat_p tPi = (cfloat_p)p.pi, tCR = (cfloat_p)p.cR, tExpT = (cfloat_p)p.expT;
+  const cint_p tStepRow = (cint_p)p.stepRow;
   const size_t vecF4 = (size_t)K4 * kWave; // float4 per stored K-vector of a wave
   float4* const chunkbuf = p.ws + (size_t)blockIdx.x * p.wsSlot;
   float4* const ckpt = chunkbuf + (size_t)p.chunk * vecF4;
@@ -279,7 +286,14 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     if (g >= (unsigned)p.nGroups) {
       break;
     }
-    const fsmc_group grp = p.groups[g];
+    const cuint_p gw = (cuint_p)(p.groups + g);
+    fsmc_group grp;
+    grp.first_pair = gw[0];
+    grp.n_pairs = gw[1];
+    grp.from = gw[2];
+    grp.to = gw[3];
+    grp.scan_from = gw[4];
+    grp.scan_to = gw[5];
     const int from = (int)grp.from;
     const int to = (int)grp.to;
     const int scanFrom = (int)grp.scan_from;
@@ -357,8 +371,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           ev = prefetchEmis(q - 1);
         }
         const int c = obsClass(q);
-        const size_t row = (size_t)p.stepRow[q] * KP;
-        beta_step<KT, KA>(K, b, w, p.D + row, p.B + row, p.U + row, p.RR + row, &emisLds[q & 1][c * K4]);
+        const size_t row = (size_t)tStepRow[q] * KP;
+        beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * K4]);
         afterBeta(pos);
       }
     }
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       const unsigned idx = atomicAdd(&p.counters[1], 1u);
       float mean = 0.f, mapv = 0.f;
       if constexpr (TRACK) {
-        segment_ages<KT, KA>(K, p.ageThr, sps, p.pi, p.expT, (p.flags & FSMC_WANT_MEAN) != 0,
+        segment_ages<KT, KA>(K, p.ageThr, sps, tPi, tExpT, (p.flags & FSMC_WANT_MEAN) != 0,
                              (p.flags & FSMC_WANT_MAP) != 0, mean, mapv);
       }
       if (idx < p.recCap) {
@@ -424,8 +438,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               ev = prefetchEmis(q - 1);
             }
             const int c = obsClass(q);
-            const size_t row = (size_t)p.stepRow[q] * KP;
-            beta_step<KT, KA>(K, b, w, p.D + row, p.B + row, p.U + row, p.RR + row, &emisLds[q & 1][c * K4]);
+            const size_t row = (size_t)tStepRow[q] * KP;
+            beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * K4]);
             store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
           }
         }
@@ -444,10 +458,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         const int c = obsClass(pos);
         const float4* e = &emisLds[pos & 1][c * K4];
         if (pos == from) {
-          alpha_init<KT, KA>(K, a, p.pi, e);
+          alpha_init<KT, KA>(K, a, tPi, e);
         } else {
-          const size_t row = (size_t)p.stepRow[pos] * KP;
-          alpha_step<KT, KA>(K, a, w, p.D + row, p.B + row, p.U + row, p.cR, e);
+          const size_t row = (size_t)tStepRow[pos] * KP;
+          alpha_step<KT, KA>(K, a, w, tD + row, tB + row, tU + row, tCR, e);
         }
 
         // combine with beta of this site and normalise (HMM.cpp:672-691)
