@@ -12,6 +12,7 @@ HIP_LIB = os.path.join(HERE, "libfastsmc_hip.so")
 HIPCC_FLAGS = [
     "-std=c++17", "-O3", "--offload-arch=gfx950",
     "-ffp-contract=off",  # parity: the reference path has no fused multiply-add
+    "-fno-slp-vectorize",  # packed-f32 SLP of the k-recurrences costs more moves than it saves
     "-fPIC", "-shared",
 ]
 

@@ -440,7 +440,7 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   }
   m->ctx = ctx;
   m->K = d->K;
-  m->KP = (d->K + 3) / 4 * 4;
+  m->KP = (d->K + kKB - 1) / kKB * kKB; // rows padded to whole operand blocks (16-byte aligned, zero filled)
   m->S = d->S;
   m->nRows = d->n_rows;
   m->stateThr = d->state_threshold;

@@ -75,6 +75,54 @@ struct KParams {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Scalar operand streaming.  The k-loops of a step are walked in blocks; each block needs a few
+// wave-uniform table values, fetched with hand-placed scalar loads into SGPRs, and this lane's emission
+// values (float4 reads from the LDS ring).  The loads of block i+1 are issued right after the wait for
+// block i, so that scalar-cache / LDS latency hides under the arithmetic of block i.  Scalar loads are
+// inline asm because the compiler otherwise merges and hoists them to the top of the sweep (hundreds
+// of spilled SGPRs) -- it cannot see these loads, so each result is only read after an explicit
+// s_waitcnt that names it as an in/out operand.  (Waits the compiler inserts for its own LDS reads stay
+// correct: extra outstanding scalar loads only make a counted lgkmcnt wait stricter.)
+// None of this changes the per-lane order of floating-point operations.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// (hipcc also parses kernel bodies in its host pass, where gfx950 asm constraints do not exist)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FSMC_GCN_ASM(...) asm volatile(__VA_ARGS__)
+#else
+#define FSMC_GCN_ASM(...) ((void)0)
+#endif
+
+__device__ __forceinline__ f32x4 sload4(cfloat_p p)
+{
+  f32x4 v = {};
+  FSMC_GCN_ASM("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p));
+  return v;
+}
+__device__ __forceinline__ f32x8 sload8(cfloat_p p)
+{
+  f32x8 v = {};
+  FSMC_GCN_ASM("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p));
+  return v;
+}
+__device__ __forceinline__ void swait(f32x8& a, f32x8& b)
+{
+  FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+}
+__device__ __forceinline__ void swait(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
+{
+  FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+}
+
+constexpr int kKB = 8;  // states per operand block of the beta passes (two tables each: 2 x 8 SGPRs, double buffered)
+constexpr int kKBF = 4; // the alpha pass streams four tables at once: 4 x 4 SGPRs, double buffered
+
+__device__ __forceinline__ float pick(const float4& e0, const float4& e1, const int i)
+{
+  return i == 0 ? e0.x : i == 1 ? e0.y : i == 2 ? e0.z : i == 3 ? e0.w : i == 4 ? e1.x : i == 5 ? e1.y : i == 6 ? e1.z : e1.w;
+}
+
 // One step of the backward recursion for one pair (HMM.cpp:957-1016, NO_SSE association).
 // b: beta of site pos+1 (scaled) on entry, beta of site pos (scaled) on exit.  w: scratch.
 // e: this lane's emission row for site pos+1 (LDS).  Dr/Br/Ur/RRr: wave-uniform table rows.
@@ -82,29 +130,70 @@ template <int KT, int KA>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
                                           cfloat_p Ur, cfloat_p RRr, const float4* e)
 {
-  const int K4 = (K + 3) >> 2;
+  const int NB = (K + kKB - 1) / kKB;
+  // descending: vec[k] = beta[k]*e[k];  BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1]  (BU[K-1] = 0)
+  f32x8 u = sload8(Ur + (NB - 1) * kKB);
+  f32x8 rr = sload8(RRr + (NB - 1) * kKB);
+  float4 e0 = e[2 * (NB - 1)];
+  float4 e1 = e[2 * (NB - 1) + 1];
+  f32x8 d, bt; // operands of the ascending pass; its first block is requested during the last descending block
 #pragma unroll
-  for (int k4 = 0; k4 < K4; ++k4) {
-    const float4 ev = e[k4];
-    if (4 * k4 + 0 < K) b[4 * k4 + 0] = b[4 * k4 + 0] * ev.x;
-    if (4 * k4 + 1 < K) b[4 * k4 + 1] = b[4 * k4 + 1] * ev.y;
-    if (4 * k4 + 2 < K) b[4 * k4 + 2] = b[4 * k4 + 2] * ev.z;
-    if (4 * k4 + 3 < K) b[4 * k4 + 3] = b[4 * k4 + 3] * ev.w;
-  }
-  w[K - 1] = 0.f;
+  for (int blk = NB - 1; blk >= 0; --blk) {
+    swait(u, rr);
+    f32x8 nu = u, nrr = rr;
+    float4 n0 = e0, n1 = e1;
+    if (blk > 0) {
+      nu = sload8(Ur + (blk - 1) * kKB);
+      nrr = sload8(RRr + (blk - 1) * kKB);
+      n0 = e[2 * (blk - 1)];
+      n1 = e[2 * (blk - 1) + 1];
+    } else {
+      d = sload8(Dr);
+      bt = sload8(Br);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k = K - 2; k >= 0; --k) {
-    w[k] = Ur[k] * b[k + 1] + RRr[k] * w[k + 1];
+    for (int i = kKB - 1; i >= 0; --i) {
+      const int k = blk * kKB + i;
+      if (k < K) {
+        b[k] = b[k] * pick(e0, e1, i);
+        if (k == K - 1) {
+          w[k] = 0.f;
+        } else {
+          w[k] = u[i] * b[k + 1] + rr[i] * w[k + 1];
+        }
+      }
+    }
+    u = nu;
+    rr = nrr;
+    e0 = n0;
+    e1 = n1;
   }
+  // ascending: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k]
   float BL = 0.f;
   float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (k) {
-      BL = BL + Br[k - 1] * b[k - 1];
+  for (int blk = 0; blk < NB; ++blk) {
+    swait(d, bt);
+    f32x8 nd = d, nbt = bt;
+    if (blk + 1 < NB) {
+      nd = sload8(Dr + (blk + 1) * kKB);
+      nbt = sload8(Br + (blk + 1) * kKB);
     }
-    w[k] = (BL + Dr[k] * b[k]) + w[k];
-    sum = sum + w[k];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < kKB; ++i) {
+      const int k = blk * kKB + i;
+      if (k < K) {
+        w[k] = (BL + d[i] * b[k]) + w[k];
+        sum = sum + w[k];
+        if (k < K - 1) {
+          BL = BL + bt[i] * b[k];
+        }
+      }
+    }
+    d = nd;
+    bt = nbt;
   }
   const float c = 1.0f / sum;
 #pragma unroll
@@ -119,6 +208,12 @@ template <int KT, int KA>
 __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
                                            cfloat_p Ur, cfloat_p cR, const float4* e)
 {
+  const int NB = (K + kKBF - 1) / kKBF;
+  // first operand block requested before the operand-free suffix-sum pass
+  f32x4 d = sload4(Dr), bt = sload4(Br), u = sload4(Ur), c4 = sload4(cR);
+  float4 e0 = e[0];
+  __builtin_amdgcn_sched_barrier(0);
+  // alphaC[k] = sum_{i>=k} alpha[i], accumulated from the top (HMM.cpp:799-814)
   w[K - 1] = a[K - 1];
 #pragma unroll
   for (int k = K - 2; k >= 0; --k) {
@@ -126,22 +221,40 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
   }
   float AU = 0.f;
   float sum = 0.f;
-  float4 ev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if ((k & 3) == 0) {
-      ev = e[k >> 2];
+  for (int blk = 0; blk < NB; ++blk) {
+    swait(d, bt, u, c4);
+    f32x4 nd = d, nbt = bt, nu = u, nc = c4;
+    float4 n0 = e0;
+    if (blk + 1 < NB) {
+      nd = sload4(Dr + (blk + 1) * kKBF);
+      nbt = sload4(Br + (blk + 1) * kKBF);
+      nu = sload4(Ur + (blk + 1) * kKBF);
+      nc = sload4(cR + (blk + 1) * kKBF);
+      n0 = e[blk + 1];
     }
-    if (k) {
-      AU = Ur[k - 1] * a[k - 1] + cR[k - 1] * AU;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < kKBF; ++i) {
+      const int k = blk * kKBF + i;
+      if (k < K) {
+        float term = AU + d[i] * a[k];
+        if (k < K - 1) {
+          term = term + bt[i] * w[k + 1];
+        }
+        const float em = i == 0 ? e0.x : i == 1 ? e0.y : i == 2 ? e0.z : e0.w;
+        w[k] = em * term;
+        sum = sum + w[k];
+        if (k < K - 1) {
+          AU = u[i] * a[k] + c4[i] * AU; // AU of state k+1
+        }
+      }
     }
-    float term = AU + Dr[k] * a[k];
-    if (k < K - 1) {
-      term = term + Br[k] * w[k + 1];
-    }
-    const float em = (k & 3) == 0 ? ev.x : (k & 3) == 1 ? ev.y : (k & 3) == 2 ? ev.z : ev.w;
-    w[k] = em * term;
-    sum = sum + w[k];
+    d = nd;
+    bt = nbt;
+    u = nu;
+    c4 = nc;
+    e0 = n0;
   }
   const float c = 1.0f / sum;
 #pragma unroll
@@ -260,11 +373,15 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 {
   constexpr int KA = KT > 0 ? KT : kMaxGenericK;
   constexpr int K4A = (KA + 3) / 4;
+  constexpr int E4A = ((KA + kKB - 1) / kKB) * (kKB / 4); // float4 per emission row (rows padded to kKB)
+  constexpr int NL = (3 * E4A + kWave - 1) / kWave;       // float4 per lane to stage one site's rows
   const int K = KT > 0 ? KT : p.K;
   const int K4 = (K + 3) >> 2;
   const int KP = p.KP;
+  const int E4 = KP >> 2;
 
-  __shared__ float4 emisLds[2][3 * K4A];
+  __shared__ float4 emisLds[2][3 * E4A];  // ring of two sites x three observation classes
+  __shared__ float4 betaLds[K4A * kWave]; // landing zone of the next site's beta row (LDS-DMA)
 
   const int lane = threadIdx.x;
   const cfloat_p tD = (cfloat_p)p.D, tB = (cfloat_p)p.B, tU = (cfloat_p)p.U, tRR = (cfloat_p)p.RR;
@@ -277,6 +394,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   float4* const saveS = saveA + vecF4;
   const int C = p.chunk;
 
+  struct EmisRegs {
+    float4 v[NL];
+  };
+
   for (;;) {
     unsigned g = 0;
     if (lane == 0) {
@@ -287,19 +408,14 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       break;
     }
     const cuint_p gw = (cuint_p)(p.groups + g);
-    fsmc_group grp;
-    grp.first_pair = gw[0];
-    grp.n_pairs = gw[1];
-    grp.from = gw[2];
-    grp.to = gw[3];
-    grp.scan_from = gw[4];
-    grp.scan_to = gw[5];
-    const int from = (int)grp.from;
-    const int to = (int)grp.to;
-    const int scanFrom = (int)grp.scan_from;
-    const int aEnd = (MODE == kModeIbd) ? (int)grp.scan_to : to; // the alpha sweep stops here
-    const bool valid = lane < (int)grp.n_pairs;
-    const unsigned pairIdx = grp.first_pair + (valid ? (unsigned)lane : 0u);
+    const unsigned firstPair = gw[0];
+    const int nPairsInGroup = (int)gw[1];
+    const int from = (int)gw[2];
+    const int to = (int)gw[3];
+    const int scanFrom = (int)gw[4];
+    const int aEnd = (MODE == kModeIbd) ? (int)gw[5] : to; // the alpha sweep stops here
+    const bool valid = lane < nPairsInGroup;
+    const unsigned pairIdx = firstPair + (valid ? (unsigned)lane : 0u);
     const fsmc_pair pr = p.pairs[pairIdx];
     const unsigned long long* rowA = p.haps + (size_t)pr.hap_a * p.W;
     const unsigned long long* rowB = p.haps + (size_t)pr.hap_b * p.W;
@@ -326,16 +442,25 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       const int t = (int)((aw >> bit) & 1ull);
       return x ? 0 : 1 + t;
     };
-    auto prefetchEmis = [&](const int q) -> float4 {
-      float4 v = {0.f, 0.f, 0.f, 0.f};
-      if (lane < 3 * K4) {
-        v = p.emis3[(size_t)q * (3 * K4) + lane];
+    auto prefetchEmis = [&](const int q) -> EmisRegs {
+      EmisRegs r;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int idx = lane + i * kWave;
+        r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < 3 * E4) {
+          r.v[i] = p.emis3[(size_t)q * (3 * E4) + idx];
+        }
       }
-      return v;
+      return r;
     };
-    auto commitEmis = [&](const int q, const float4 v) {
-      if (lane < 3 * K4) {
-        emisLds[q & 1][lane] = v;
+    auto commitEmis = [&](const int q, const EmisRegs& r) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int idx = lane + i * kWave;
+        if (idx < 3 * E4) {
+          emisLds[q & 1][idx] = r.v[i];
+        }
       }
       __builtin_amdgcn_wave_barrier();
     };
@@ -360,7 +485,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
       };
       afterBeta(to - 1);
-      float4 ev = {0.f, 0.f, 0.f, 0.f};
+      EmisRegs ev;
       if (to - 2 >= from) {
         ev = prefetchEmis(to - 1);
       }
@@ -372,7 +497,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
         const int c = obsClass(q);
         const size_t row = (size_t)tStepRow[q] * KP;
-        beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * K4]);
+        beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4]);
         afterBeta(pos);
       }
     }
@@ -406,6 +531,15 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         p.recs[idx] = r;
       }
     };
+    // LDS-DMA of one stored beta row (K4 x 1 KiB) into the landing zone: asynchronous, no VGPRs
+    auto fetchBeta = [&](const float4* src) {
+#pragma unroll
+      for (int k4 = 0; k4 < K4; ++k4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_global_load_lds(src + (size_t)k4 * kWave, &betaLds[k4 * kWave], 16, 0, 0);
+#endif
+      }
+    };
 
     for (int j = 0; j < (nChunks > 0 ? nChunks : 0); ++j) {
       const int lo = from + j * C;
@@ -427,7 +561,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             load_vec<KT, KA>(K, ckpt + (size_t)(j + 1) * vecF4 + lane, b);
             pos = hi - 1;
           }
-          float4 ev = {0.f, 0.f, 0.f, 0.f};
+          EmisRegs ev;
           if (pos >= lo) {
             ev = prefetchEmis(pos + 1);
           }
@@ -439,7 +573,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
             const int c = obsClass(q);
             const size_t row = (size_t)tStepRow[q] * KP;
-            beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * K4]);
+            beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4]);
             store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
           }
         }
@@ -449,14 +583,18 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
       }
 
-      float4 ev = prefetchEmis(lo);
+      // the wave's own stores of this chunk's betas must have landed before the DMA reads them back
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
+      fetchBeta(chunkbuf + lane);
+      EmisRegs ev = prefetchEmis(lo);
       for (int pos = lo; pos < hi; ++pos) {
         commitEmis(pos, ev);
         if (pos + 1 < hi) {
           ev = prefetchEmis(pos + 1);
         }
         const int c = obsClass(pos);
-        const float4* e = &emisLds[pos & 1][c * K4];
+        const float4* e = &emisLds[pos & 1][c * E4];
         if (pos == from) {
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
@@ -464,28 +602,46 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           alpha_step<KT, KA>(K, a, w, tD + row, tB + row, tU + row, tCR, e);
         }
 
-        // combine with beta of this site and normalise (HMM.cpp:672-691)
-        const float4* bsrc = chunkbuf + (size_t)(pos - lo) * vecF4 + lane;
+        // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
+        FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         float sumq = 0.f;
+        {
+          const int NB = (K + kKB - 1) / kKB;
+          auto loadB = [&](const int blk, float4& b0, float4& b1) {
+            b0 = betaLds[(2 * blk) * kWave + lane];
+            b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (2 * blk + 1 < K4) {
+              b1 = betaLds[(2 * blk + 1) * kWave + lane];
+            }
+          };
+          float4 c0, c1;
+          loadB(0, c0, c1);
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) {
-          const float4 bv = bsrc[(size_t)k4 * kWave];
-          w[4 * k4] = a[4 * k4] * bv.x;
-          sumq = sumq + w[4 * k4];
-          if (4 * k4 + 1 < K) {
-            w[4 * k4 + 1] = a[4 * k4 + 1] * bv.y;
-            sumq = sumq + w[4 * k4 + 1];
-          }
-          if (4 * k4 + 2 < K) {
-            w[4 * k4 + 2] = a[4 * k4 + 2] * bv.z;
-            sumq = sumq + w[4 * k4 + 2];
-          }
-          if (4 * k4 + 3 < K) {
-            w[4 * k4 + 3] = a[4 * k4 + 3] * bv.w;
-            sumq = sumq + w[4 * k4 + 3];
+          for (int blk = 0; blk < NB; ++blk) {
+            float4 n0 = c0, n1 = c1;
+            if (blk + 1 < NB) {
+              loadB(blk + 1, n0, n1);
+            }
+#pragma unroll
+            for (int i = 0; i < kKB; ++i) {
+              const int k = blk * kKB + i;
+              if (k < K) {
+                w[k] = a[k] * pick(c0, c1, i);
+                sumq = sumq + w[k];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = n0;
+            c1 = n1;
           }
         }
         const float cq = 1.0f / sumq;
+        // every read of the landing zone has returned: request the next site's beta row
+        FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (pos + 1 < hi) {
+          fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4 + lane);
+        }
 
         if (MODE == kModeDump) {
           float* out = p.dumpOut + p.dumpOffsets[g] + (size_t)(pos - from) * K * kWave + lane;
@@ -499,6 +655,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           if (pos >= scanFrom) {
             // posterior of the states the scan needs
             const unsigned nPost = TRACK ? (p.ageThr > p.stateThr ? p.ageThr : p.stateThr) : p.stateThr;
+            // (guards instead of early exits: a data-dependent trip count would turn the register
+            //  arrays into dynamically indexed scratch memory)
 #pragma unroll
             for (int k4 = 0; k4 < K4; ++k4) {
               if ((unsigned)(4 * k4) < nPost) {
@@ -510,8 +668,13 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              if ((unsigned)k < p.stateThr) s = s + w[k];
+            for (int k4 = 0; k4 < K4; ++k4) {
+              if ((unsigned)(4 * k4) < p.stateThr) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  if (4 * k4 + i < K && (unsigned)(4 * k4 + i) < p.stateThr) s = s + w[4 * k4 + i];
+                }
+              }
             }
             const int level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
             // a change of level (or a drop below every threshold) closes the open segment at pos-1
@@ -522,8 +685,14 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             if constexpr (TRACK) {
               if (level != 4) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                  if ((unsigned)k < p.ageThr) sps[k] = (opening ? 0.f : sps[k]) + w[k];
+                for (int k4 = 0; k4 < K4; ++k4) {
+                  if ((unsigned)(4 * k4) < p.ageThr) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      const int k = 4 * k4 + i;
+                      if (k < K && (unsigned)k < p.ageThr) sps[k] = (opening ? 0.f : sps[k]) + w[k];
+                    }
+                  }
                 }
               }
             }
