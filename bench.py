@@ -170,6 +170,7 @@ def main() -> None:
         elapsed = float(t.item())
 
     info = ctx.info()
+    phase = ctx.phase_cycles()
     if rank == 0:
         total_pairs = n_pairs * world * args.steps
         value = total_pairs / elapsed
@@ -185,7 +186,8 @@ def main() -> None:
             "config": {"workload": f"synthetic {args.haps} haplotypes x {args.sites} sites, K={pm.K}, all "
                                    f"{n_pairs} pairs per GPU, FastSMC-mode IBD + posterior-mean/MAP ages, no hashing",
                        "pair_sites_per_s": value * pm.S, "ibd_records_per_step": n_rec,
-                       "resident_waves": info["n_slots"], "n_cu": info["n_cu"]},
+                       "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
+                       **({"phase_cycles": [int(x) for x in phase]} if phase.any() else {})},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
                          "kernel_ms": 1e3 * k_s, "algorithmic_bytes_per_launch": algo_bytes},

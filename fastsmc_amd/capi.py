@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfastsmc_hip.so")
+# FSMC_HIP_LIB lets a profiling run point at an experimental build of the same ABI
+LIB_PATH = os.environ.get("FSMC_HIP_LIB") or os.path.join(_HERE, "libfastsmc_hip.so")
 
 FSMC_WANT_MEAN = 1
 FSMC_WANT_MAP = 2
@@ -26,7 +27,8 @@ FSMC_EOVERFLOW = -6
 SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
-    "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_decode_ibd",
+    "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
+    "fsmc_decode_ibd",
     "fsmc_decode_posteriors", "fsmc_decode_per_pair", "fsmc_decode_sums",
 ]
 
@@ -83,6 +85,7 @@ def load():
         L.fsmc_decode_ibd_fetch.argtypes = [vp, vp, sz, C.POINTER(sz)]
         L.fsmc_sync.argtypes = [vp]
         L.fsmc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.fsmc_phase_cycles.argtypes = [vp, vp, sz]
         L.fsmc_decode_ibd.argtypes = [vp, vp, vp, sz, vp, sz, u32, vp, sz, C.POINTER(sz)]
         L.fsmc_decode_posteriors.argtypes = [vp, vp, vp, sz]
         L.fsmc_decode_per_pair.argtypes = [vp, vp, vp, vp, vp]
@@ -186,6 +189,11 @@ class Context:
         ms = C.c_float()
         self._check(self._L.fsmc_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def phase_cycles(self) -> np.ndarray:
+        out = np.zeros(8, np.uint64)
+        self._check(self._L.fsmc_phase_cycles(self._h, _p(out), 8))
+        return out
 
     def decode_ibd(self, model: "Model", pairs, groups, flags: int = FSMC_WANT_MEAN | FSMC_WANT_MAP) -> np.ndarray:
         self.upload_worklist(pairs, groups)

@@ -48,6 +48,7 @@ struct fsmc_ctx {
   std::vector<fsmc_group> hGroups;
 
   unsigned* dCounters = nullptr;
+  unsigned long long* dPhase = nullptr;
   DevBuf ws;
   DevBuf recs;
   size_t recCap = 0;
@@ -277,6 +278,7 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.pairs = ctx->dPairs;
   p.groups = ctx->dGroups;
   p.counters = ctx->dCounters;
+  p.phaseCycles = ctx->dPhase;
   p.ws = (float4*)ctx->ws.p;
   p.wsSlot = plan.wsSlot;
   p.stateThr = m->stateThr;
@@ -357,6 +359,8 @@ int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->dCounters, 4 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->dPhase, 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(ctx->dPhase, 0, 8 * sizeof(unsigned long long));
   if (e != hipSuccess) {
     std::string msg = std::string("context set-up failed: ") + hipGetErrorString(e);
     fsmc_ctx_destroy(ctx);
@@ -379,6 +383,7 @@ void fsmc_ctx_destroy(fsmc_ctx* ctx)
   if (ctx->dPairs) (void)hipFree(ctx->dPairs);
   if (ctx->dGroups) (void)hipFree(ctx->dGroups);
   if (ctx->dCounters) (void)hipFree(ctx->dCounters);
+  if (ctx->dPhase) (void)hipFree(ctx->dPhase);
   if (ctx->ws.p) (void)hipFree(ctx->ws.p);
   if (ctx->recs.p) (void)hipFree(ctx->recs.p);
   if (ctx->aux.p) (void)hipFree(ctx->aux.p);
@@ -440,7 +445,7 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   }
   m->ctx = ctx;
   m->K = d->K;
-  m->KP = (d->K + kKB - 1) / kKB * kKB; // rows padded to whole operand blocks (16-byte aligned, zero filled)
+  m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
   m->S = d->S;
   m->nRows = d->n_rows;
   m->stateThr = d->state_threshold;
@@ -625,6 +630,17 @@ int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms)
   }
   FSMC_HIP(ctx, hipEventSynchronize(ctx->ev1));
   FSMC_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return FSMC_OK;
+}
+
+int fsmc_phase_cycles(fsmc_ctx* ctx, uint64_t* out, size_t n)
+{
+  if (!ctx || !out || n > 8) {
+    return fail(ctx, FSMC_EINVAL, "bad argument");
+  }
+  FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FSMC_HIP(ctx, hipMemcpy(out, ctx->dPhase, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  FSMC_HIP(ctx, hipMemset(ctx->dPhase, 0, 8 * sizeof(unsigned long long)));
   return FSMC_OK;
 }
 

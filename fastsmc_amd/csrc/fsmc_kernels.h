@@ -33,6 +33,9 @@ constexpr int kWave = 64;
 typedef const float __attribute__((address_space(4))) * cfloat_p;
 typedef const int __attribute__((address_space(4))) * cint_p;
 typedef const unsigned __attribute__((address_space(4))) * cuint_p;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMaxGenericK = 256; // upper bound on K for the generic (runtime-K) kernel
 
 enum Mode : int { kModeIbd = 0, kModeDump = 1, kModePerPair = 2, kModeSums = 3 };
@@ -70,6 +73,7 @@ struct KParams {
   float* ppMean;              // kModePerPair: [nPairs][S]
   int* ppMap;                 // kModePerPair: [nPairs][S]
   const float* expCoal;       // kModePerPair: [KP]
+  unsigned long long* phaseCycles; // diagnostic builds (-DFSMC_PHASE_STAMPS): [0] pass B, [1] rebuild, [2] alpha sweep, [3] groups
   float* sums;                // kModeSums: per-slot accumulators [slots][S][K] (+ 00/01/11 planes)
   size_t sumsPlane;           // floats per plane per slot
 };
@@ -84,9 +88,6 @@ struct KParams {
 // s_waitcnt that names it as an in/out operand.  (Waits the compiler inserts for its own LDS reads stay
 // correct: extra outstanding scalar loads only make a counted lgkmcnt wait stricter.)
 // None of this changes the per-lane order of floating-point operations.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-
 // (hipcc also parses kernel bodies in its host pass, where gfx950 asm constraints do not exist)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FSMC_GCN_ASM(...) asm volatile(__VA_ARGS__)
@@ -106,21 +107,77 @@ __device__ __forceinline__ f32x8 sload8(cfloat_p p)
   FSMC_GCN_ASM("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p));
   return v;
 }
+#define FSMC_SWAIT_INSN "s_waitcnt lgkmcnt(0)"
+__device__ __forceinline__ f32x16 sload16(cfloat_p p)
+{
+  f32x16 v = {};
+  FSMC_GCN_ASM("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p));
+  return v;
+}
 __device__ __forceinline__ void swait(f32x8& a, f32x8& b)
 {
-  FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+  FSMC_GCN_ASM(FSMC_SWAIT_INSN : "+s"(a), "+s"(b));
 }
+__device__ __forceinline__ void swait(f32x16& a, f32x16& b)
+{
+  FSMC_GCN_ASM(FSMC_SWAIT_INSN : "+s"(a), "+s"(b));
+}
+__device__ __forceinline__ void swait(f32x8& a, f32x8& b, f32x8& c, f32x8& d)
+{
+  FSMC_GCN_ASM(FSMC_SWAIT_INSN : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+}
+// block-width dispatch so the block sizes below are tunable
+template <int N> struct SV;
+template <> struct SV<4> { typedef f32x4 T; static __device__ __forceinline__ T load(cfloat_p p) { return sload4(p); } };
+template <> struct SV<8> { typedef f32x8 T; static __device__ __forceinline__ T load(cfloat_p p) { return sload8(p); } };
+template <> struct SV<16> { typedef f32x16 T; static __device__ __forceinline__ T load(cfloat_p p) { return sload16(p); } };
 __device__ __forceinline__ void swait(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
 {
-  FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+  FSMC_GCN_ASM(FSMC_SWAIT_INSN : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
 }
 
-constexpr int kKB = 8;  // states per operand block of the beta passes (two tables each: 2 x 8 SGPRs, double buffered)
-constexpr int kKBF = 4; // the alpha pass streams four tables at once: 4 x 4 SGPRs, double buffered
+#if defined(FSMC_PHASE_STAMPS)
+#define FSMC_SWAIT(acc, ...)                                                                                           \
+  do {                                                                                                                 \
+    const long long t0_ = (long long)clock64();                                                                        \
+    swait(__VA_ARGS__);                                                                                                \
+    (acc) += (long long)clock64() - t0_;                                                                               \
+  } while (0)
+#else
+#define FSMC_SWAIT(acc, ...) swait(__VA_ARGS__)
+#endif
+
+#ifndef FSMC_KB
+#define FSMC_KB 8
+#endif
+#ifndef FSMC_KBF
+#define FSMC_KBF 4
+#endif
+constexpr int kKB = FSMC_KB;   // states per operand block of the beta passes (two tables at a time)
+constexpr int kKBF = FSMC_KBF; // states per operand block of the alpha pass (four tables at a time)
+constexpr int kKPad = 16;      // table / emission rows are zero padded to a multiple of this many floats
 
 __device__ __forceinline__ float pick(const float4& e0, const float4& e1, const int i)
 {
   return i == 0 ? e0.x : i == 1 ? e0.y : i == 2 ? e0.z : i == 3 ? e0.w : i == 4 ? e1.x : i == 5 ? e1.y : i == 6 ? e1.z : e1.w;
+}
+
+template <int N> struct EmisBlk { // this lane's emission values of one operand block (N/4 float4 from LDS)
+  float4 v[N / 4];
+  __device__ __forceinline__ float at(const int i) const
+  {
+    const float4& q = v[i >> 2];
+    return (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
+  }
+};
+template <int N> __device__ __forceinline__ EmisBlk<N> readEmis(const float4* e, const int blk)
+{
+  EmisBlk<N> r;
+#pragma unroll
+  for (int j = 0; j < N / 4; ++j) {
+    r.v[j] = e[blk * (N / 4) + j];
+  }
+  return r;
 }
 
 // One step of the backward recursion for one pair (HMM.cpp:957-1016, NO_SSE association).
@@ -128,35 +185,34 @@ __device__ __forceinline__ float pick(const float4& e0, const float4& e1, const 
 // e: this lane's emission row for site pos+1 (LDS).  Dr/Br/Ur/RRr: wave-uniform table rows.
 template <int KT, int KA>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                          cfloat_p Ur, cfloat_p RRr, const float4* e)
+                                          cfloat_p Ur, cfloat_p RRr, const float4* e, long long& waitCycles)
 {
+  typedef typename SV<kKB>::T SVec;
   const int NB = (K + kKB - 1) / kKB;
   // descending: vec[k] = beta[k]*e[k];  BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1]  (BU[K-1] = 0)
-  f32x8 u = sload8(Ur + (NB - 1) * kKB);
-  f32x8 rr = sload8(RRr + (NB - 1) * kKB);
-  float4 e0 = e[2 * (NB - 1)];
-  float4 e1 = e[2 * (NB - 1) + 1];
-  f32x8 d, bt; // operands of the ascending pass; its first block is requested during the last descending block
+  SVec u = SV<kKB>::load(Ur + (NB - 1) * kKB);
+  SVec rr = SV<kKB>::load(RRr + (NB - 1) * kKB);
+  EmisBlk<kKB> em = readEmis<kKB>(e, NB - 1);
+  SVec d, bt; // operands of the ascending pass; its first block is requested during the last descending block
 #pragma unroll
   for (int blk = NB - 1; blk >= 0; --blk) {
-    swait(u, rr);
-    f32x8 nu = u, nrr = rr;
-    float4 n0 = e0, n1 = e1;
+    FSMC_SWAIT(waitCycles, u, rr);
+    SVec nu = u, nrr = rr;
+    EmisBlk<kKB> nem = em;
     if (blk > 0) {
-      nu = sload8(Ur + (blk - 1) * kKB);
-      nrr = sload8(RRr + (blk - 1) * kKB);
-      n0 = e[2 * (blk - 1)];
-      n1 = e[2 * (blk - 1) + 1];
+      nu = SV<kKB>::load(Ur + (blk - 1) * kKB);
+      nrr = SV<kKB>::load(RRr + (blk - 1) * kKB);
+      nem = readEmis<kKB>(e, blk - 1);
     } else {
-      d = sload8(Dr);
-      bt = sload8(Br);
+      d = SV<kKB>::load(Dr);
+      bt = SV<kKB>::load(Br);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = kKB - 1; i >= 0; --i) {
       const int k = blk * kKB + i;
       if (k < K) {
-        b[k] = b[k] * pick(e0, e1, i);
+        b[k] = b[k] * em.at(i);
         if (k == K - 1) {
           w[k] = 0.f;
         } else {
@@ -166,19 +222,18 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
     }
     u = nu;
     rr = nrr;
-    e0 = n0;
-    e1 = n1;
+    em = nem;
   }
   // ascending: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k]
   float BL = 0.f;
   float sum = 0.f;
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
-    swait(d, bt);
-    f32x8 nd = d, nbt = bt;
+    FSMC_SWAIT(waitCycles, d, bt);
+    SVec nd = d, nbt = bt;
     if (blk + 1 < NB) {
-      nd = sload8(Dr + (blk + 1) * kKB);
-      nbt = sload8(Br + (blk + 1) * kKB);
+      nd = SV<kKB>::load(Dr + (blk + 1) * kKB);
+      nbt = SV<kKB>::load(Br + (blk + 1) * kKB);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -206,12 +261,13 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
 // (HmmUtils.cpp:102-151).  a: alpha of site pos-1 on entry, of site pos on exit.
 template <int KT, int KA>
 __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                           cfloat_p Ur, cfloat_p cR, const float4* e)
+                                           cfloat_p Ur, cfloat_p cR, const float4* e, long long& waitCycles)
 {
+  typedef typename SV<kKBF>::T SVec;
   const int NB = (K + kKBF - 1) / kKBF;
   // first operand block requested before the operand-free suffix-sum pass
-  f32x4 d = sload4(Dr), bt = sload4(Br), u = sload4(Ur), c4 = sload4(cR);
-  float4 e0 = e[0];
+  SVec d = SV<kKBF>::load(Dr), bt = SV<kKBF>::load(Br), u = SV<kKBF>::load(Ur), c4 = SV<kKBF>::load(cR);
+  EmisBlk<kKBF> em = readEmis<kKBF>(e, 0);
   __builtin_amdgcn_sched_barrier(0);
   // alphaC[k] = sum_{i>=k} alpha[i], accumulated from the top (HMM.cpp:799-814)
   w[K - 1] = a[K - 1];
@@ -223,15 +279,15 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
   float sum = 0.f;
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
-    swait(d, bt, u, c4);
-    f32x4 nd = d, nbt = bt, nu = u, nc = c4;
-    float4 n0 = e0;
+    FSMC_SWAIT(waitCycles, d, bt, u, c4);
+    SVec nd = d, nbt = bt, nu = u, nc = c4;
+    EmisBlk<kKBF> nem = em;
     if (blk + 1 < NB) {
-      nd = sload4(Dr + (blk + 1) * kKBF);
-      nbt = sload4(Br + (blk + 1) * kKBF);
-      nu = sload4(Ur + (blk + 1) * kKBF);
-      nc = sload4(cR + (blk + 1) * kKBF);
-      n0 = e[blk + 1];
+      nd = SV<kKBF>::load(Dr + (blk + 1) * kKBF);
+      nbt = SV<kKBF>::load(Br + (blk + 1) * kKBF);
+      nu = SV<kKBF>::load(Ur + (blk + 1) * kKBF);
+      nc = SV<kKBF>::load(cR + (blk + 1) * kKBF);
+      nem = readEmis<kKBF>(e, blk + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -242,8 +298,7 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
         if (k < K - 1) {
           term = term + bt[i] * w[k + 1];
         }
-        const float em = i == 0 ? e0.x : i == 1 ? e0.y : i == 2 ? e0.z : e0.w;
-        w[k] = em * term;
+        w[k] = em.at(i) * term;
         sum = sum + w[k];
         if (k < K - 1) {
           AU = u[i] * a[k] + c4[i] * AU; // AU of state k+1
@@ -254,7 +309,7 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
     bt = nbt;
     u = nu;
     c4 = nc;
-    e0 = n0;
+    em = nem;
   }
   const float c = 1.0f / sum;
 #pragma unroll
@@ -313,7 +368,9 @@ template <int KT, int KA> __device__ __forceinline__ void store_vec(const int K,
     o.y = (4 * k4 + 1 < K) ? v[4 * k4 + 1] : 0.f;
     o.z = (4 * k4 + 2 < K) ? v[4 * k4 + 2] : 0.f;
     o.w = (4 * k4 + 3 < K) ? v[4 * k4 + 3] : 0.f;
-    dst[(size_t)k4 * kWave] = o;
+    // streamed once, read back once: keep it from evicting the model tables out of L2
+    const f32x4 ov = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(&dst[(size_t)k4 * kWave]));
   }
 }
 
@@ -322,7 +379,8 @@ template <int KT, int KA> __device__ __forceinline__ void load_vec(const int K, 
   const int K4 = (K + 3) >> 2;
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) {
-    const float4 o = src[(size_t)k4 * kWave];
+    const f32x4 ov = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(&src[(size_t)k4 * kWave]));
+    const float4 o = make_float4(ov.x, ov.y, ov.z, ov.w);
     v[4 * k4] = o.x;
     if (4 * k4 + 1 < K) v[4 * k4 + 1] = o.y;
     if (4 * k4 + 2 < K) v[4 * k4 + 2] = o.z;
@@ -373,7 +431,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 {
   constexpr int KA = KT > 0 ? KT : kMaxGenericK;
   constexpr int K4A = (KA + 3) / 4;
-  constexpr int E4A = ((KA + kKB - 1) / kKB) * (kKB / 4); // float4 per emission row (rows padded to kKB)
+  constexpr int E4A = ((KA + kKPad - 1) / kKPad) * (kKPad / 4); // float4 per emission row (rows padded to kKPad)
   constexpr int NL = (3 * E4A + kWave - 1) / kWave;       // float4 per lane to stage one site's rows
   const int K = KT > 0 ? KT : p.K;
   const int K4 = (K + 3) >> 2;
@@ -466,6 +524,20 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     };
 
     float w[KA];
+    long long cycW = 0; // cycles parked in operand waits (diagnostic builds only)
+#if defined(FSMC_PHASE_STAMPS)
+    // diagnostic build only: where a group's wall time goes (never enabled in the shipped library)
+    long long cycB = 0, cycR = 0, cycA = 0;
+    long long stamp = (long long)clock64();
+#define FSMC_STAMP(acc)                                                                                                \
+  do {                                                                                                                 \
+    const long long now_ = (long long)clock64();                                                                       \
+    (acc) += now_ - stamp;                                                                                             \
+    stamp = now_;                                                                                                      \
+  } while (0)
+#else
+#define FSMC_STAMP(acc) ((void)0)
+#endif
 
     // ------------------------------------------------------------------ pass B
     {
@@ -497,11 +569,12 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
         const int c = obsClass(q);
         const size_t row = (size_t)tStepRow[q] * KP;
-        beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4]);
+        beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
         afterBeta(pos);
       }
     }
 
+    FSMC_STAMP(cycB);
     // ------------------------------------------------------------------ pass A
     int cur = 4;      // open threshold level (0..3) or 4 = none
     int segStart = 0; // first site of the open segment
@@ -536,7 +609,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 #pragma unroll
       for (int k4 = 0; k4 < K4; ++k4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_global_load_lds(src + (size_t)k4 * kWave, &betaLds[k4 * kWave], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + (size_t)k4 * kWave, &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
 #endif
       }
     };
@@ -573,7 +646,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
             const int c = obsClass(q);
             const size_t row = (size_t)tStepRow[q] * KP;
-            beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4]);
+            beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
             store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
           }
         }
@@ -583,6 +656,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
       }
 
+      FSMC_STAMP(cycR);
       // the wave's own stores of this chunk's betas must have landed before the DMA reads them back
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
@@ -599,7 +673,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
           const size_t row = (size_t)tStepRow[pos] * KP;
-          alpha_step<KT, KA>(K, a, w, tD + row, tB + row, tU + row, tCR, e);
+          alpha_step<KT, KA>(K, a, w, tD + row, tB + row, tU + row, tCR, e, cycW);
         }
 
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
@@ -607,7 +681,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         __builtin_amdgcn_wave_barrier();
         float sumq = 0.f;
         {
-          const int NB = (K + kKB - 1) / kKB;
+          constexpr int kCB = 8; // states per block of the combine
+          const int NB = (K + kCB - 1) / kCB;
           auto loadB = [&](const int blk, float4& b0, float4& b1) {
             b0 = betaLds[(2 * blk) * kWave + lane];
             b1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -624,8 +699,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               loadB(blk + 1, n0, n1);
             }
 #pragma unroll
-            for (int i = 0; i < kKB; ++i) {
-              const int k = blk * kKB + i;
+            for (int i = 0; i < kCB; ++i) {
+              const int k = blk * kCB + i;
               if (k < K) {
                 w[k] = a[k] * pick(c0, c1, i);
                 sumq = sumq + w[k];
@@ -709,7 +784,17 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           }
         }
       }
+      FSMC_STAMP(cycA);
     }
+#if defined(FSMC_PHASE_STAMPS)
+    if (lane == 0 && p.phaseCycles) {
+      atomicAdd(&p.phaseCycles[0], (unsigned long long)cycB);
+      atomicAdd(&p.phaseCycles[1], (unsigned long long)cycR);
+      atomicAdd(&p.phaseCycles[2], (unsigned long long)cycA);
+      atomicAdd(&p.phaseCycles[3], 1ull);
+      atomicAdd(&p.phaseCycles[4], (unsigned long long)cycW);
+    }
+#endif
   }
 }
 

@@ -129,6 +129,10 @@ int fsmc_sync(fsmc_ctx* ctx);
 /* Device time (ms, hipEvent) of the last decode launch's kernel(s); valid after a sync/fetch. */
 int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms);
 
+/* Diagnostic: shader-clock cycles summed over waves since the last call, {pass B, beta rebuild, alpha sweep,
+ * groups}; all zero unless the library was built with -DFSMC_PHASE_STAMPS (never the shipped build). */
+int fsmc_phase_cycles(fsmc_ctx* ctx, uint64_t* out, size_t n);
+
 /* Convenience: upload work list + launch + fetch. */
 int fsmc_decode_ibd(fsmc_ctx* ctx, const fsmc_model* m, const fsmc_pair* pairs, size_t n_pairs,
                     const fsmc_group* groups, size_t n_groups, uint32_t flags, fsmc_ibd_record* out, size_t cap,
