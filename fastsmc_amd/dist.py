@@ -1,0 +1,45 @@
+"""Multi-GPU plumbing for the decode path: one process per GPU (``torch.distributed``; backend "nccl" is
+RCCL on ROCm, "gloo" in CPU tests).  Pairs are independent, so the pair list is sharded with no collective
+on the data path; the only exchange is the final gather of variable-length IBD records to rank 0."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_pair_range(n_pairs: int, rank: int, world: int, batch: int = 64) -> tuple[int, int]:
+    """Contiguous shard [lo, hi) of the pair list for this rank, cut at batch boundaries so that every
+    reference batch (HMM.cpp:555-591) stays on one device.  Same split rule as the reference's job ranges
+    (pairs * r / R, HMM.cpp:319-321), applied to batches."""
+    n_batches = (n_pairs + batch - 1) // batch
+    lo_b = n_batches * rank // world
+    hi_b = n_batches * (rank + 1) // world
+    return min(lo_b * batch, n_pairs), min(hi_b * batch, n_pairs)
+
+
+def gather_ibd_records(rec: np.ndarray, pair_offset: int, dist, rank: int, world: int, device="cpu"):
+    """Gather every rank's IBD records (structured array with a ``pair`` field holding *local* pair indices) to
+    rank 0: all_gather of counts, then gather of padded byte payloads.  Returns (total_count, records_or_None);
+    on rank 0 the records carry global pair indices and are ordered like a single-device run."""
+    import torch
+
+    local = rec.copy()
+    local["pair"] += np.uint32(pair_offset)
+    if dist is None or world == 1:
+        return int(local.size), local
+    cnt = torch.tensor([local.size], device=device, dtype=torch.int64)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    item = local.dtype.itemsize
+    payload = torch.zeros(max(mx, 1) * item, dtype=torch.uint8, device=device)
+    if local.size:
+        payload[: local.nbytes] = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(device)
+    bucket = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+    dist.gather(payload, bucket, dst=0)
+    if rank != 0:
+        return sum(counts), None
+    parts = [bucket[r][: counts[r] * item].cpu().numpy().view(local.dtype) for r in range(world)]
+    out = np.concatenate(parts) if parts else local[:0]
+    # shards are contiguous and each is already ordered, so concatenation is the single-device order
+    return sum(counts), out

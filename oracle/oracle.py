@@ -393,3 +393,53 @@ def decode_pairs_ibd(model: PreparedModel, hap_bytes: np.ndarray, pairs, *, batc
             recs.append(ibd_scan_pair(model, post, v, 0, S, want_mean=want_mean, want_map=want_map,
                                       pair_ordinal=b0 + v))
     return np.concatenate(recs) if recs else np.zeros(0, IBD_DTYPE)
+
+
+# ----------------------------------------------------- record formatting (HMM.cpp:1110-1144)
+
+def _g7(x) -> str:
+    """C++ ostream << with setprecision(7) (std::numeric_limits<float>::digits10 + 1), default float field."""
+    return format(float(x), ".7g")
+
+
+def format_ibd_text(recs: np.ndarray, pairs, fam_ids, iids, chr_number: int, phys, gen, *, want_length=True,
+                    want_mean=True, want_map=True) -> str:
+    """Text lines HMM::writePairIBD writes for these records; ``pairs[i] = (hapRowA, hapRowB)`` and a haplotype
+    row r is individual r // 2, haplotype r % 2 + 1."""
+    lines = []
+    gen = np.asarray(gen, np.float32)
+    for r in recs:
+        ha, hb = pairs[int(r["pair"])]
+        ia, ib = ha // 2, hb // 2
+        f = [fam_ids[ia], iids[ia], str(ha % 2 + 1), fam_ids[ib], iids[ib], str(hb % 2 + 1), str(chr_number),
+             str(int(phys[r["start"]])), str(int(phys[r["end"]]))]
+        if want_length:
+            f.append(_g7(np.float32(100.0) * np.float32(gen[r["end"]] - gen[r["start"]])))
+        f.append(_g7(float(np.float32(r["prob"])) / float(int(r["end"]) - int(r["start"]) + 1)))
+        if want_mean:
+            f.append(_g7(r["postMean"]))
+        if want_map:
+            f.append(_g7(r["map"]))
+        lines.append("\t".join(f) + "\n")
+    return "".join(lines)
+
+
+def job_individuals(sample_size: int, jobs: int, job_ind: int):
+    """Individuals a job loads (Data.cpp:62-80, 251-262): windows w_i, w_j of the square job grid."""
+    import math
+
+    window = math.ceil(math.sqrt((2.0 * sample_size ** 2 - sample_size) * 2.0 / jobs))
+    if window % 2:
+        window += 1
+    w_i, cpt_job, cpt_tot = 1, 1, 1
+    while cpt_tot < job_ind:
+        w_i += 1
+        cpt_job += 2
+        cpt_tot += cpt_job
+    w_j = math.ceil(np.float32(cpt_job - (cpt_tot - job_ind)) / 2)
+    keep = []
+    for d in range(sample_size):
+        if ((w_i - 1) * window // 2 <= d < w_i * window // 2) or ((w_j - 1) * window // 2 <= d < w_j * window // 2) \
+                or (jobs == job_ind and d >= (w_j - 1) * window // 2):
+            keep.append(d)
+    return keep

@@ -1,0 +1,147 @@
+"""End-to-end through the product's host API (pybind11 classes over the C ABI) on a real GPU:
+FastSMC-mode runs must write byte-identical IBD text to what the oracle + the reference's record
+format give, including the job-slicing of the pinned no-hashing regression shape (job 7 of 9)."""
+import copy
+import gzip
+
+import numpy as np
+import pytest
+
+from fastsmc_amd import api, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def files(small_problem, tmp_path_factory):
+    sp = small_problem
+    root = str(tmp_path_factory.mktemp("data") / "syn")
+    synth.write_haps_files(root, sp["haps"])
+    used = np.unique(np.concatenate([[0.0], O.step_rows(sp["tables"].keys, sp["gen"])[1][1:]]))
+    t = copy.copy(sp["tables"])
+    sel = np.nonzero(np.isin(t.keys, used.astype(np.float32)))[0]
+    t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
+    synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
+    return root
+
+
+def _params(root, out, **kw):
+    p = api.DecodingParams()
+    p.inFileRoot = root
+    p.decodingQuantFile = root + ".decodingQuantities.gz"
+    p.outFileRoot = out
+    p.decodingModeString = "array"
+    p.foldData = True
+    p.usingCSFS = True
+    p.batchSize = 32
+    p.recallThreshold = 3
+    p.min_m = 1.5
+    p.hashing = False
+    p.FastSMC = True
+    p.BIN_OUT = False
+    p.outputIbdSegmentLength = True
+    p.time = 50
+    p.noConditionalAgeEstimates = True
+    p.doPerPairMAP = True
+    p.doPerPairPosteriorMean = True
+    p.useKnownSeed = True
+    for k, v in kw.items():
+        setattr(p, k, v)
+    assert p.validateParamsFastSMC()
+    return p
+
+
+def _oracle_text(sp, individuals, jobs, job_ind):
+    """What the reference would write: subset of individuals (job windows), pair slice, batches of 32."""
+    haps = sp["haps"]
+    rows = np.array([2 * d + h for d in individuals for h in (0, 1)])
+    alleles = haps.alleles  # folding uses ALL samples of the file (Data.cpp:465-471)
+    _, derived, flipped = synth.fold_and_pack(alleles)
+    folded_all = np.where(flipped[None, :], 1 - alleles, alleles).astype(np.uint8)
+    folded = folded_all[rows]
+    pm = O.prepare_model(sp["tables"], sp["gen"], haps.bp, derived, alleles.shape[0], time=50)
+    pairs = O.enumerate_all_pairs(len(individuals), jobs, job_ind)
+    recs = O.decode_pairs_ibd(pm, folded, pairs, batch_size=32)
+    ids = [f"1_{d + 1}" for d in individuals]
+    return O.format_ibd_text(recs, pairs, ids, ids, 1, haps.bp, sp["gen"]), len(pairs)
+
+
+def test_fastsmc_run_matches_oracle_text(files, small_problem, tmp_path):
+    out = str(tmp_path / "res")
+    p = _params(files, out)
+    api.FastSMC(p).run()
+    got = gzip.open(out + ".1.1.FastSMC.ibd.gz", "rt").read()
+    want, n_pairs = _oracle_text(small_problem, list(range(32)), 1, 1)
+    assert n_pairs == 2 * 32 * 32 - 32
+    assert want.count("\n") > 100
+    assert got == want
+
+
+def test_fastsmc_job_7_of_9_matches_oracle_text(files, small_problem, tmp_path):
+    """Shape of the reference's no-hashing regression (test_fastsmc_regression.cpp:97-161): jobInd 7 of 9 loads a
+    subset of individuals (Data.cpp:62-80) and decodes a slice of that subset's pairs (HMM.cpp:319-321)."""
+    out = str(tmp_path / "res79")
+    p = _params(files, out, jobs=9, jobInd=7)
+    f = api.FastSMC(p)
+    f.run()
+    got = gzip.open(out + ".7.9.FastSMC.ibd.gz", "rt").read()
+    individuals = O.job_individuals(32, 9, 7)
+    want, _ = _oracle_text(small_problem, individuals, 9, 7)
+    assert got == want and want
+
+
+def test_hmm_decode_single_pair_matches_oracle_posterior(files, small_problem, tmp_path):
+    p = _params(files, str(tmp_path / "x"))
+    data = api.Data(p)
+    hmm = api.HMM(data, p)
+    obs = hmm.makePairObs(1, 0, 2, 5)  # haplotype rows 0 and 11
+    post = np.array(hmm.decode(obs), np.float32)  # [K][S]
+    sp = small_problem
+    ob = (sp["folded"][0] ^ sp["folded"][11])[None, :]
+    hb = (sp["folded"][0] & sp["folded"][11])[None, :]
+    want, _ = O.decode_batch(sp["model"], ob, hb, 0, sp["model"].S)
+    np.testing.assert_array_equal(post, want[:, :, 0].T)
+    assert np.array_equal(np.array(obs.obsBits, np.uint8), ob[0])
+
+
+def test_decode_from_hashing_batches_windows_like_the_reference(files, small_problem, tmp_path):
+    """Candidates pushed through HMM.decodeFromHashing: batch windows = union of the batch's candidate windows
+    padded by 0.5 cM; every pair scanned over the un-padded union (HMM.cpp:470-502, 555-636, 1199-1206)."""
+    out = str(tmp_path / "hash")
+    p = _params(files, out, hashing=True)
+    data = api.Data(p)
+    hmm = api.HMM(data, p)
+    hmm.setKeepIbdRecords(True)
+    hmm.decodeAll(1, 1)
+    rng = np.random.default_rng(5)
+    S = small_problem["model"].S
+    cands = []
+    for _ in range(75):  # 2 full batches of 32 + a ragged one of 11
+        a, b = sorted(rng.choice(64, 2, replace=False))
+        f = int(rng.integers(0, S - 120))
+        t = f + int(rng.integers(40, 110))
+        cands.append((int(a), int(b), f, t))
+        hmm.decodeFromHashing(int(a), int(b), f, t)
+    hmm.finishFromHashing()
+    got = hmm.getIbdRecords()
+    sp = small_problem
+    pm, gen, folded = sp["model"], sp["gen"], sp["folded"]
+    want = []
+    for b0 in range(0, len(cands), 32):
+        batch = cands[b0:b0 + 32]
+        start = min(c[2] for c in batch)
+        end = max(c[3] for c in batch)
+        frm, to = O.get_from_position(gen, start), O.get_to_position(gen, end)
+        ob = np.stack([(folded[a] ^ folded[b])[frm:to] for a, b, _, _ in batch])
+        hb = np.stack([(folded[a] & folded[b])[frm:to] for a, b, _, _ in batch])
+        while ob.shape[0] % 4:
+            ob = np.concatenate([ob, ob[-1:]])
+            hb = np.concatenate([hb, hb[-1:]])
+        post, _ = O.decode_batch(pm, ob, hb, frm, to)
+        for v in range(len(batch)):
+            for r in O.ibd_scan_pair(pm, post, v, start, end, pair_ordinal=b0 + v):
+                want.append((batch[v][0], batch[v][1], int(r["start"]), int(r["end"]), float(r["prob"]),
+                             float(r["postMean"]), float(r["map"])))
+    assert len(want) > 10
+    assert [tuple(x) for x in got] == want
