@@ -200,6 +200,22 @@ class Context:
         self.decode_ibd_launch(model, flags)
         return self.decode_ibd_fetch()
 
+    def decode_per_pair(self, model: "Model", exp_coal_times, want_mean=True, want_map=True):
+        """writePerPairOutput for the resident work list: (mean[n_pairs][S] f32, map[n_pairs][S] i32)."""
+        et = np.ascontiguousarray(exp_coal_times, np.float32)
+        mean = np.zeros((self._n_pairs, model.S), np.float32) if want_mean else None
+        mp = np.zeros((self._n_pairs, model.S), np.int32) if want_map else None
+        self._check(self._L.fsmc_decode_per_pair(self._h, model._h, _p(et), _p(mean), _p(mp)))
+        return mean, mp
+
+    def decode_sums(self, model: "Model", major_minor: bool = False, sums: bool = True):
+        """augmentSumOverPairs for the resident work list: arrays [S][K] (sum, and 00/01/11 when asked)."""
+        shape = (model.S, model.K)
+        s = np.zeros(shape, np.float32) if sums else None
+        mm = [np.zeros(shape, np.float32) for _ in range(3)] if major_minor else [None, None, None]
+        self._check(self._L.fsmc_decode_sums(self._h, model._h, _p(s), _p(mm[0]), _p(mm[1]), _p(mm[2])))
+        return s, mm
+
     def decode_posteriors(self, model: "Model") -> list[np.ndarray]:
         """Posterior per group in the reference's batch layout: list of [to-from][K][64] arrays."""
         gr = self._groups

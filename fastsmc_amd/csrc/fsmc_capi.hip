@@ -165,6 +165,10 @@ KernelFn pickKernel(int mode, bool track, int K)
     return track ? pickKernel<kModeIbd, true>(K) : pickKernel<kModeIbd, false>(K);
   case kModeDump:
     return pickKernel<kModeDump, false>(K);
+  case kModePerPair:
+    return pickKernel<kModePerPair, false>(K);
+  case kModeSums:
+    return pickKernel<kModeSums, false>(K);
   default:
     return nullptr;
   }
@@ -742,14 +746,114 @@ int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_
   return FSMC_OK;
 }
 
-int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model*, const float*, float*, int32_t*)
+int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model* m, const float* exp_coal_times, float* mean, int32_t* map)
 {
-  return fail(ctx, FSMC_EUNSUPPORTED, "fsmc_decode_per_pair: not built yet");
+  int rc = checkReady(ctx, m);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  if (!exp_coal_times || (!mean && !map)) {
+    return fail(ctx, FSMC_EINVAL, "need expected coalescence times and at least one output");
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  KernelFn fn = pickKernel(kModePerPair, false, m->K);
+  LaunchPlan plan;
+  rc = planLaunch(ctx, m, kModePerPair, fn, plan);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  const size_t n = ctx->nPairs * (size_t)m->S;
+  const size_t coalBytes = (size_t)m->KP * sizeof(float);
+  // layout of the staging buffer: [expCoal KP floats][mean n floats][map n ints]
+  rc = ensure(ctx, ctx->out, coalBytes + n * (sizeof(float) + sizeof(int32_t)));
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  std::vector<float> coal((size_t)m->KP, 0.f);
+  std::memcpy(coal.data(), exp_coal_times, sizeof(float) * (size_t)m->K);
+  char* base = (char*)ctx->out.p;
+  FSMC_HIP(ctx, hipMemcpyAsync(base, coal.data(), coalBytes, hipMemcpyHostToDevice, ctx->stream));
+  FSMC_HIP(ctx, hipMemsetAsync(base + coalBytes, 0, n * (sizeof(float) + sizeof(int32_t)), ctx->stream));
+  KParams p;
+  fillParams(ctx, m, plan, 0, p);
+  p.expCoal = (const float*)base;
+  p.ppMean = mean ? (float*)(base + coalBytes) : nullptr;
+  p.ppMap = map ? (int*)(base + coalBytes + n * sizeof(float)) : nullptr;
+  rc = launch(ctx, fn, p, plan.slots);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (mean) {
+    FSMC_HIP(ctx, hipMemcpy(mean, p.ppMean, n * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  if (map) {
+    FSMC_HIP(ctx, hipMemcpy(map, p.ppMap, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return FSMC_OK;
 }
 
-int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model*, float*, float*, float*, float*)
+int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sums00, float* sums01, float* sums11)
 {
-  return fail(ctx, FSMC_EUNSUPPORTED, "fsmc_decode_sums: not built yet");
+  int rc = checkReady(ctx, m);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  const bool mm = sums00 || sums01 || sums11;
+  if (!sums && !mm) {
+    return fail(ctx, FSMC_EINVAL, "no output requested");
+  }
+  if (mm && !(sums00 && sums01 && sums11)) {
+    return fail(ctx, FSMC_EINVAL, "the 00/01/11 sums come together");
+  }
+  for (const fsmc_group& g : ctx->hGroups) {
+    if (g.from != 0 || g.to != (uint32_t)m->S) {
+      return fail(ctx, FSMC_EINVAL, "posterior sums need whole-sequence groups (HMM.cpp:1052)");
+    }
+  }
+  if ((size_t)m->K * 65 * sizeof(float) > (size_t)((m->K > 69 ? kMaxGenericK : 69) + 3) / 4 * kWave * sizeof(float4)) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "too many states for the sums transposition tile");
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  KernelFn fn = pickKernel(kModeSums, false, m->K);
+  LaunchPlan plan;
+  rc = planLaunch(ctx, m, kModeSums, fn, plan);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  const size_t plane = (size_t)m->S * m->K;
+  const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.25 * (double)ctx->hbmBytes);
+  size_t slots = (size_t)plan.slots;
+  slots = std::max<size_t>(1, std::min<size_t>(slots, limit / (4 * plane * sizeof(float))));
+  rc = ensure(ctx, ctx->out, (slots + 1) * 4 * plane * sizeof(float));
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  FSMC_HIP(ctx, hipMemsetAsync(ctx->out.p, 0, (slots + 1) * 4 * plane * sizeof(float), ctx->stream));
+  KParams p;
+  fillParams(ctx, m, plan, (sums ? FSMC_WANT_SUMS : 0u) | (mm ? FSMC_WANT_MAJOR_MINOR_SUMS : 0u), p);
+  p.sums = (float*)ctx->out.p;
+  p.sumsPlane = plane;
+  rc = launch(ctx, fn, p, (int)slots);
+  if (rc != FSMC_OK) {
+    return rc;
+  }
+  float* reduced = (float*)ctx->out.p + slots * 4 * plane;
+  hipLaunchKernelGGL(reduce_planes_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const float*)ctx->out.p, reduced,
+                     4 * plane, (int)slots, 4 * plane);
+  FSMC_HIP(ctx, hipGetLastError());
+  FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<float> host(4 * plane);
+  FSMC_HIP(ctx, hipMemcpy(host.data(), reduced, 4 * plane * sizeof(float), hipMemcpyDeviceToHost));
+  float* dst[4] = {sums, sums00, sums01, sums11};
+  for (int q = 0; q < 4; ++q) {
+    if (dst[q]) {
+      for (size_t i = 0; i < plane; ++i) {
+        dst[q][i] += host[(size_t)q * plane + i]; // accumulates, like sumOverPairs(pos,k) += sum (HMM.cpp:1073)
+      }
+    }
+  }
+  return FSMC_OK;
 }
 
 } // extern "C"

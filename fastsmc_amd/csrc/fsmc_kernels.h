@@ -456,12 +456,18 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     float4 v[NL];
   };
 
-  for (;;) {
+  for (unsigned round = 0;; ++round) {
     unsigned g = 0;
-    if (lane == 0) {
-      g = atomicAdd(&p.counters[0], 1u);
+    if (MODE == kModeSums) {
+      // each resident wave owns an accumulator plane and takes groups slot, slot + nSlots, ... in order, so the
+      // order of float additions is fixed from run to run
+      g = blockIdx.x + round * gridDim.x;
+    } else {
+      if (lane == 0) {
+        g = atomicAdd(&p.counters[0], 1u);
+      }
+      g = __builtin_amdgcn_readfirstlane(g);
     }
-    g = __builtin_amdgcn_readfirstlane(g);
     if (g >= (unsigned)p.nGroups) {
       break;
     }
@@ -714,8 +720,77 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         const float cq = 1.0f / sumq;
         // every read of the landing zone has returned: request the next site's beta row
         FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (pos + 1 < hi) {
+        if (MODE != kModeSums && pos + 1 < hi) {
           fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4 + lane);
+        }
+
+        if (MODE == kModePerPair) {
+          // HMM::writePerPairOutput (HMM.cpp:1378-1409): mean = sum_k post*E[t_k] (k ascending from 0.f),
+          // MAP = first strictly larger posterior
+          const cfloat_p tCoal = (cfloat_p)p.expCoal;
+          float mean = 0.f;
+          float best = 0.f;
+          int arg = 0;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const float post = w[k] * cq;
+            mean = mean + post * tCoal[k];
+            if (best < post) {
+              arg = k;
+              best = post;
+            }
+          }
+          if (valid) {
+            if (p.ppMean) p.ppMean[(size_t)pairIdx * p.S + pos] = mean;
+            if (p.ppMap) p.ppMap[(size_t)pairIdx * p.S + pos] = arg;
+          }
+        }
+
+        if (MODE == kModeSums) {
+          // HMM::augmentSumOverPairs (HMM.cpp:1052-1081): per site and state, the batch's posteriors are summed
+          // over pairs in batch order (local fp32 sum from 0.f), then added to the accumulator.  The K x 64 tile
+          // is transposed through LDS (row stride 65 floats: conflict-free both ways); lane j then owns state j.
+          float* const tile = reinterpret_cast<float*>(betaLds);
+          unsigned char* const cls = reinterpret_cast<unsigned char*>(&emisLds[(pos + 1) & 1][0]); // idle ring slot
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            tile[k * 65 + lane] = w[k] * cq;
+          }
+          if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+            cls[lane] = (unsigned char)c;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (int kk = lane; kk < K; kk += kWave) {
+            float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
+            for (int v = 0; v < nPairsInGroup; ++v) {
+              const float q = tile[kk * 65 + v];
+              s = s + q;
+              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                const int cv = cls[v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
+                if (cv == 2) {
+                  s11 = s11 + q;
+                } else if (cv == 1) {
+                  s00 = s00 + q;
+                } else {
+                  s01 = s01 + q;
+                }
+              }
+            }
+            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + kk;
+            if (p.flags & FSMC_WANT_SUMS) acc[0] += s;
+            if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+              acc[p.sumsPlane] += s00;
+              acc[2 * p.sumsPlane] += s01;
+              acc[3 * p.sumsPlane] += s11;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          if (pos + 1 < hi) {
+            fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4 + lane);
+          }
         }
 
         if (MODE == kModeDump) {
@@ -795,6 +870,20 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       atomicAdd(&p.phaseCycles[4], (unsigned long long)cycW);
     }
 #endif
+  }
+}
+
+
+// Sum of the per-wave accumulator planes in slot order (fixed order => reproducible fp32 result).
+__global__ void reduce_planes_kernel(const float* __restrict__ planes, float* __restrict__ out, size_t n, int nSlots,
+                                     size_t slotStride)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int sl = 0; sl < nSlots; ++sl) {
+      s = s + planes[(size_t)sl * slotStride + i];
+    }
+    out[i] = s;
   }
 }
 
