@@ -8,10 +8,11 @@ from __future__ import annotations
 import numpy as np
 
 from . import _pyasmc
-from ._pyasmc import (ASMC, Data, DecodePairsReturnStruct, DecodingMode, DecodingModeOverall,  # noqa: F401
-                      DecodingParams, DecodingQuantities, DecodingReturnValues, FastSMC, HMM, PairObservations)
+from ._pyasmc import (ASMC, BinaryDataReader, Data, DecodePairsReturnStruct, DecodingMode, DecodingModeOverall,  # noqa: F401
+                      DecodingParams, DecodingQuantities, DecodingReturnValues, FastSMC, HMM, IbdPairDataLine,
+                      PairObservations)
 
-__all__ = ["ASMC", "Data", "DecodePairsReturnStruct", "DecodingMode", "DecodingModeOverall", "DecodingParams",
+__all__ = ["ASMC", "BinaryDataReader", "IbdPairDataLine", "Data", "DecodePairsReturnStruct", "DecodingMode", "DecodingModeOverall", "DecodingParams",
            "DecodingQuantities", "DecodingReturnValues", "FastSMC", "HMM", "PairObservations",
            "decoding_quantities_from_tables", "PreparedModelView"]
 

@@ -6,6 +6,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include "binary_reader.hpp"
 #include "drivers.hpp"
 
 namespace py = pybind11;
@@ -249,6 +250,28 @@ PYBIND11_MODULE(_pyasmc, m)
       .def_readwrite("withinOnly", &DecodingParams::withinOnly)
       .def_readwrite("doMajorMinorPosteriorSums", &DecodingParams::doMajorMinorPosteriorSums)
       .def_readwrite("gpuDevice", &DecodingParams::gpuDevice);
+
+  py::class_<IbdPairDataLine>(m, "IbdPairDataLine")
+      .def(py::init<>())
+      .def_readwrite("ind1FamId", &IbdPairDataLine::ind1FamId)
+      .def_readwrite("ind1Id", &IbdPairDataLine::ind1Id)
+      .def_readwrite("ind1Hap", &IbdPairDataLine::ind1Hap)
+      .def_readwrite("ind2FamId", &IbdPairDataLine::ind2FamId)
+      .def_readwrite("ind2Id", &IbdPairDataLine::ind2Id)
+      .def_readwrite("ind2Hap", &IbdPairDataLine::ind2Hap)
+      .def_readwrite("chromosome", &IbdPairDataLine::chromosome)
+      .def_readwrite("ibdStart", &IbdPairDataLine::ibdStart)
+      .def_readwrite("ibdEnd", &IbdPairDataLine::ibdEnd)
+      .def_readwrite("lengthInCentimorgans", &IbdPairDataLine::lengthInCentimorgans)
+      .def_readwrite("ibdScore", &IbdPairDataLine::ibdScore)
+      .def_readwrite("postEst", &IbdPairDataLine::postEst)
+      .def_readwrite("mapEst", &IbdPairDataLine::mapEst)
+      .def("toString", &IbdPairDataLine::toString);
+
+  py::class_<BinaryDataReader>(m, "BinaryDataReader")
+      .def(py::init<const std::string&>(), "binaryFile"_a)
+      .def("getNextLine", &BinaryDataReader::getNextLine)
+      .def("moreLinesInFile", &BinaryDataReader::moreLinesInFile);
 
   py::class_<Data>(m, "Data")
       .def(py::init<const DecodingParams&>(), "params"_a)

@@ -145,3 +145,23 @@ def test_decode_from_hashing_batches_windows_like_the_reference(files, small_pro
                              float(r["postMean"]), float(r["map"])))
     assert len(want) > 10
     assert [tuple(x) for x in got] == want
+
+
+def test_binary_output_round_trip(files, small_problem, tmp_path):
+    """BIN_OUT writes the .bibd.gz layout of HMM.cpp:383-401 / 1146-1176; read it back with BinaryDataReader and
+    compare with the text run (ibd_score is fp32 in the binary file, double in the text file)."""
+    out_b = str(tmp_path / "bin")
+    out_t = str(tmp_path / "txt")
+    api.FastSMC(_params(files, out_b, BIN_OUT=True)).run()
+    api.FastSMC(_params(files, out_t)).run()
+    text = gzip.open(out_t + ".1.1.FastSMC.ibd.gz", "rt").read().splitlines()
+    rd = api.BinaryDataReader(out_b + ".1.1.FastSMC.bibd.gz")
+    n = 0
+    while rd.moreLinesInFile():
+        line = rd.getNextLine()
+        t = text[n].split("\t")
+        b = line.toString().split("\t")
+        assert b[:10] == t[:10] and b[11:] == t[11:]
+        assert float(b[10]) == pytest.approx(float(t[10]), rel=1e-6)
+        n += 1
+    assert n == len(text) and n > 100
