@@ -194,18 +194,27 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
   SVec rr = SV<kKB>::load(RRr + (NB - 1) * kKB);
   EmisBlk<kKB> em = readEmis<kKB>(e, NB - 1);
   SVec d, bt; // operands of the ascending pass; its first block is requested during the last descending block
+  // With a runtime K these loops are real loops: a register holding a scalar load still in flight must not be
+  // copied across the back-edge, so the generic instantiation loads and waits per block instead of prefetching.
 #pragma unroll
   for (int blk = NB - 1; blk >= 0; --blk) {
+    if (KT == 0 && blk < NB - 1) {
+      u = SV<kKB>::load(Ur + blk * kKB);
+      rr = SV<kKB>::load(RRr + blk * kKB);
+      em = readEmis<kKB>(e, blk);
+    }
     FSMC_SWAIT(waitCycles, u, rr);
     SVec nu = u, nrr = rr;
     EmisBlk<kKB> nem = em;
-    if (blk > 0) {
-      nu = SV<kKB>::load(Ur + (blk - 1) * kKB);
-      nrr = SV<kKB>::load(RRr + (blk - 1) * kKB);
-      nem = readEmis<kKB>(e, blk - 1);
-    } else {
-      d = SV<kKB>::load(Dr);
-      bt = SV<kKB>::load(Br);
+    if (KT > 0) {
+      if (blk > 0) {
+        nu = SV<kKB>::load(Ur + (blk - 1) * kKB);
+        nrr = SV<kKB>::load(RRr + (blk - 1) * kKB);
+        nem = readEmis<kKB>(e, blk - 1);
+      } else {
+        d = SV<kKB>::load(Dr);
+        bt = SV<kKB>::load(Br);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -229,9 +238,13 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
   float sum = 0.f;
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
+    if (KT == 0) {
+      d = SV<kKB>::load(Dr + blk * kKB);
+      bt = SV<kKB>::load(Br + blk * kKB);
+    }
     FSMC_SWAIT(waitCycles, d, bt);
     SVec nd = d, nbt = bt;
-    if (blk + 1 < NB) {
+    if (KT > 0 && blk + 1 < NB) {
       nd = SV<kKB>::load(Dr + (blk + 1) * kKB);
       nbt = SV<kKB>::load(Br + (blk + 1) * kKB);
     }
@@ -279,10 +292,17 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
   float sum = 0.f;
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
+    if (KT == 0 && blk > 0) {
+      d = SV<kKBF>::load(Dr + blk * kKBF);
+      bt = SV<kKBF>::load(Br + blk * kKBF);
+      u = SV<kKBF>::load(Ur + blk * kKBF);
+      c4 = SV<kKBF>::load(cR + blk * kKBF);
+      em = readEmis<kKBF>(e, blk);
+    }
     FSMC_SWAIT(waitCycles, d, bt, u, c4);
     SVec nd = d, nbt = bt, nu = u, nc = c4;
     EmisBlk<kKBF> nem = em;
-    if (blk + 1 < NB) {
+    if (KT > 0 && blk + 1 < NB) {
       nd = SV<kKBF>::load(Dr + (blk + 1) * kKBF);
       nbt = SV<kKBF>::load(Br + (blk + 1) * kKBF);
       nu = SV<kKBF>::load(Ur + (blk + 1) * kKBF);

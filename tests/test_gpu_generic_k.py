@@ -1,0 +1,65 @@
+"""The runtime-K kernel instantiation (any K <= 256; K = 69 has its own unrolled instantiation) against the
+oracle: config-4-style wide models and small ones, all output modes."""
+import numpy as np
+import pytest
+
+from fastsmc_amd import capi, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(K, n_hap=64, S=200, seed=11):
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(n_hap, S, seed=seed, cm_per_mb=25.0, switch_per_cm=0.6)
+    bits, derived, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    gen = (haps.cm / 100.0).astype(np.float32)
+    pm = O.prepare_model(tables, gen, haps.bp, derived, n_hap, time=200)
+    return pm, bits, folded
+
+
+@pytest.mark.parametrize("K", [5, 16, 70, 256])
+def test_generic_kernel_matches_oracle(K):
+    pm, bits, folded = _problem(K)
+    pairs = O.enumerate_all_pairs(32)[:96]
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    groups = capi.whole_sequence_groups(len(pairs), pm.S)
+    # IBD records (mean + MAP)
+    want = O.decode_pairs_ibd(pm, folded, pairs, batch_size=64)
+    got = ctx.decode_ibd(model, pr, groups)
+    assert got.size == want.size
+    for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"),
+                          ("post_mean", "postMean"), ("map", "map")):
+        np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f_got)
+    # posterior, per-pair mean/MAP and sums for the first group
+    ctx.upload_worklist(pr[:64], capi.whole_sequence_groups(64, pm.S))
+    post = ctx.decode_posteriors(model)[0]
+    ob = np.stack([folded[a] ^ folded[b] for a, b in pairs[:64]])
+    hb = np.stack([folded[a] & folded[b] for a, b in pairs[:64]])
+    wpost, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
+    np.testing.assert_array_equal(post, wpost)
+    mean, mp = ctx.decode_per_pair(model, pm.exp_times)
+    wmean, wmap, _ = O.per_pair_output(pm, wpost, 64)
+    np.testing.assert_array_equal(mean, wmean)
+    np.testing.assert_array_equal(mp, wmap)
+    if K <= 250:
+        s, _ = ctx.decode_sums(model)
+        wsum = np.zeros((pm.S, pm.K), np.float32)
+        O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
+        np.testing.assert_array_equal(s, wsum)
+    ctx.close()
+
+
+def test_too_many_states_is_rejected():
+    pm, bits, _ = _problem(16)
+    ctx = capi.Context(0)
+    import copy
+    big = copy.copy(pm)
+    big.K = 300
+    with pytest.raises(capi.FsmcError):
+        ctx.create_model(big)
+    ctx.close()
