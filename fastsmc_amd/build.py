@@ -39,7 +39,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 
 HOST_DIR = os.path.join(CSRC, "host")
-HOST_SOURCES = ["decoding_quantities.cpp", "decoding_params.cpp", "data.cpp", "hmm.cpp", "drivers.cpp",
+HOST_SOURCES = ["decoding_quantities.cpp", "decoding_params.cpp", "data.cpp", "hmm.cpp", "hashing.cpp", "drivers.cpp",
                 "pybind_module.cpp"]
 
 

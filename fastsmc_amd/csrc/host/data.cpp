@@ -169,6 +169,7 @@ void Data::readSamplesList(const std::string& inFileRoot, int jobID, int jobs)
       FamIDList.push_back(t[0]);
       IIDList.push_back(t[1]);
       famAndIndNameList.push_back(t[0] + "\t" + t[1]);
+      globalIndIndex.push_back(linesProcessed);
     }
     linesProcessed++;
   }
@@ -462,6 +463,7 @@ Data Data::fromArrays(const uint8_t* alleles, size_t nHaps, size_t nSites, const
     d.FamIDList.push_back(id);
     d.IIDList.push_back(id);
     d.famAndIndNameList.push_back(id + "\t" + id);
+    d.globalIndIndex.push_back(static_cast<unsigned>(i));
   }
   d.allocateBits();
   d.totalSamplesCount.assign(nSites, static_cast<int>(nHaps));

@@ -40,6 +40,9 @@ public:
   std::vector<bool> genotypeVector(size_t hapRow) const;
   size_t numIndividuals() const { return FamIDList.size(); }
   size_t numHapRows() const { return 2 * FamIDList.size(); }
+  // number of local haplotype row r in the whole file: 2 * (sample line of its individual) + r % 2
+  unsigned globalHapId(size_t hapRow) const { return 2u * globalIndIndex[hapRow / 2] + static_cast<unsigned>(hapRow % 2); }
+  std::vector<unsigned> globalIndIndex; // sample-file line of every loaded individual
 
   std::vector<std::string> FamIDList, IIDList, famAndIndNameList;
   unsigned long sampleSize = 0;        // individuals in the file

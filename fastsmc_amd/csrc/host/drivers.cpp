@@ -1,5 +1,9 @@
 #include "drivers.hpp"
 
+#include "hashing.hpp"
+
+#include "hashing.hpp"
+
 #include <stdexcept>
 
 namespace fsmc_host
@@ -72,10 +76,9 @@ void FastSMC::run()
     mHmm.closeIBDFile();
     return;
   }
-  // The hashing pre-filter (SeedHash / ExtendHash, FastSMC.cpp:118-235) is the "next" row f1 of the scope
-  // table and is not built yet; candidates can be pushed through HMM::decodeFromHashing by the caller.
-  throw std::runtime_error("FastSMC::run with hashing=true: the hashing pre-filter is not built yet "
-                           "(set params.hashing = False, or feed candidates to HMM.decodeFromHashing)");
+  // identification step: candidate (pair, window)s -> HMM::decodeFromHashing (FastSMC.cpp:118-235)
+  runHashing(mHmm.getData(), mParams, mHmm);
+  mHmm.finishFromHashing();
 }
 
 } // namespace fsmc_host

@@ -1,0 +1,180 @@
+#include "hashing.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace fsmc_host
+{
+
+double cmBetween(const int w1, const int w2, const std::vector<float>& gen, const int wordSize)
+{
+  const std::size_t start = static_cast<std::size_t>(wordSize) * w1;
+  const std::size_t end = std::min<std::size_t>(static_cast<std::size_t>(wordSize) * w2 + wordSize - 1, gen.size() - 1ul);
+  return 100.0 * (gen[end] - gen[start]);
+}
+
+HashingPrefilter::HashingPrefilter(const Data& data, const DecodingParams& params) : mData(data), mParams(params)
+{
+  if (params.hashingWordSize != 64) {
+    throw std::runtime_error("hashingWordSize must be 64 (one packed genotype word)");
+  }
+  if (params.max_seeds != 0) {
+    throw std::runtime_error("max_seeds != 0 (sub-hashing of large seeds) is not supported");
+  }
+  mNumHaps = data.numHapRows();
+  const size_t S = static_cast<size_t>(data.sites);
+  if (params.min_maf <= 0.f) {
+    // only complete words are hashed (FastSMC.cpp:186-195: a word counts once its 64th site has been read)
+    mNumWords = S / 64;
+    mWords.resize(mNumHaps * mNumWords);
+    for (size_t h = 0; h < mNumHaps; ++h) {
+      for (size_t w = 0; w < mNumWords; ++w) {
+        mWords[h * mNumWords + w] = data.bits[h * data.wordsPerHap + w];
+      }
+    }
+  } else {
+    // sites failing the MAF filter are skipped by the word stream (FastSMC.cpp:154-172); positions derived from
+    // word numbers then count kept sites only, exactly as in the reference
+    std::vector<size_t> kept;
+    for (size_t s = 0; s < S; ++s) {
+      // FastSMC.cpp:154-166: frequency of allele '1' over every haplotype of the file
+      const int total = data.totalSamplesCount[s];
+      const int ones = (data.foldToMinorAlleles && data.siteWasFlippedDuringFolding[s])
+                           ? total - data.derivedAlleleCounts[s]
+                           : data.derivedAlleleCounts[s];
+      const auto maf = static_cast<float>(ones / static_cast<double>(total));
+      if (!(maf < params.min_maf || maf > 1 - params.min_maf)) {
+        kept.push_back(s);
+      }
+    }
+    mNumWords = kept.size() / 64;
+    mWords.assign(mNumHaps * mNumWords, 0ull);
+    for (size_t h = 0; h < mNumHaps; ++h) {
+      for (size_t i = 0; i < mNumWords * 64; ++i) {
+        if (data.genotype(h, kept[i])) {
+          mWords[h * mNumWords + i / 64] |= 1ull << (i % 64);
+        }
+      }
+    }
+  }
+}
+
+bool HashingPrefilter::pairInJob(const unsigned hapI, const unsigned hapJ) const
+{
+  // SeedHash.hpp:93-128 with ind_i = the higher and ind_j = the lower haplotype; getIdNum() is the haplotype's
+  // number in the whole file (2 * sample line + 0/1).
+  const unsigned idI = mData.globalHapId(hapI);
+  const unsigned idJ = mData.globalHapId(hapJ);
+  const unsigned ws = static_cast<unsigned>(mData.windowSize);
+  const unsigned wi = static_cast<unsigned>(mData.w_i), wj = static_cast<unsigned>(mData.w_j);
+  if (mParams.jobInd == mParams.jobs) {
+    return idI >= (wi - 1) * ws && idJ >= (wj - 1) * ws && idJ < (wj - 1) * ws + (idI - (wi - 1) * ws);
+  }
+  if ((idI >= (wi - 1) * ws && idI < wi * ws) && (idJ >= (wj - 1) * ws && idJ < wj * ws)) {
+    const bool below = idJ < (wj - 1) * ws + (idI - (wi - 1) * ws);
+    return mData.is_j_above_diag ? below : !below;
+  }
+  return false;
+}
+
+void HashingPrefilter::flush(const int priorTo, const int currentWord, const bool all,
+                             std::vector<HashingCandidate>& out)
+{
+  // ExtendHash::clearPairsPriorTo / clearAllPairs (ExtendHash.hpp:85-116) + Match::print (Match.hpp:42-52)
+  std::vector<uint64_t> done;
+  for (auto& kv : mExtend) {
+    Match& m = kv.second;
+    if (all || m.end() < priorTo) {
+      done.push_back(kv.first);
+    } else if (m.end() < currentWord) {
+      m.addGap();
+    }
+  }
+  std::sort(done.begin(), done.end()); // the defined emission order
+  for (const uint64_t key : done) {
+    const Match& m = mExtend.at(key);
+    const double mlen = cmBetween(m.start(), m.end(), mData.geneticPositions, 64);
+    if (mlen >= mParams.min_m) {
+      HashingCandidate c;
+      c.hapA = static_cast<unsigned>(key / mNumHaps);
+      c.hapB = static_cast<unsigned>(key % mNumHaps);
+      c.from = static_cast<unsigned>(m.start() * 64);
+      c.to = static_cast<unsigned>(m.end() * 64 + 63);
+      out.push_back(c);
+    }
+    mExtend.erase(key);
+  }
+}
+
+template <typename Sink> void HashingPrefilter::run(Sink&& sink)
+{
+  std::vector<std::pair<uint64_t, unsigned>> order(mNumHaps);
+  std::vector<HashingCandidate> out;
+  for (unsigned long w = 0; w < mNumWords; ++w) {
+    // SeedHash: haplotypes with the same word form a seed (SeedHash.hpp:41-45)
+    for (size_t h = 0; h < mNumHaps; ++h) {
+      order[h] = {mWords[h * mNumWords + w], static_cast<unsigned>(h)};
+    }
+    std::sort(order.begin(), order.end());
+    size_t seeds = 0;
+    for (size_t a = 0; a < mNumHaps;) {
+      size_t b = a;
+      while (b < mNumHaps && order[b].first == order[a].first) {
+        ++b;
+      }
+      ++seeds;
+      a = b;
+    }
+    const int cur = static_cast<int>(w);
+    if (static_cast<float>(seeds) / static_cast<float>(mNumHaps) > mParams.skip) {
+      for (size_t a = 0; a < mNumHaps;) {
+        size_t b = a;
+        while (b < mNumHaps && order[b].first == order[a].first) {
+          ++b;
+        }
+        for (size_t i = a; i < b; ++i) {
+          for (size_t ii = i + 1; ii < b; ++ii) {
+            const unsigned lo = order[i].second, hi = order[ii].second; // sorted: lo < hi
+            if (pairInJob(hi, lo)) {
+              // ExtendHash::extendPair (ExtendHash.hpp:73-80)
+              auto it = mExtend.emplace(static_cast<uint64_t>(lo) * mNumHaps + hi, Match(64, cur)).first;
+              it->second.extend(cur);
+            }
+          }
+        }
+        a = b;
+      }
+      out.clear();
+      flush(cur - mParams.gap, cur, false, out);
+      for (const auto& c : out) {
+        sink(c);
+      }
+    } else {
+      // low-complexity word: every open match is carried over it (ExtendHash.hpp:100-104)
+      for (auto& kv : mExtend) {
+        kv.second.setEnd(cur);
+      }
+    }
+  }
+  out.clear();
+  flush(0, 0, true, out);
+  for (const auto& c : out) {
+    sink(c);
+  }
+}
+
+void runHashing(const Data& data, const DecodingParams& params, HMM& hmm)
+{
+  HashingPrefilter pf(data, params);
+  pf.run([&](const HashingCandidate& c) { hmm.decodeFromHashing(c.hapA, c.hapB, c.from, c.to); });
+}
+
+std::vector<HashingCandidate> hashingCandidates(const Data& data, const DecodingParams& params)
+{
+  HashingPrefilter pf(data, params);
+  std::vector<HashingCandidate> all;
+  pf.run([&](const HashingCandidate& c) { all.push_back(c); });
+  return all;
+}
+
+} // namespace fsmc_host

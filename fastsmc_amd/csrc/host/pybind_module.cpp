@@ -8,6 +8,7 @@
 
 #include "binary_reader.hpp"
 #include "drivers.hpp"
+#include "hashing.hpp"
 
 namespace py = pybind11;
 using namespace py::literals;
@@ -405,6 +406,23 @@ PYBIND11_MODULE(_pyasmc, m)
       .def("get_ref_of_results", &ASMC::getRefOfResults, py::return_value_policy::reference_internal)
       .def("hmm", &ASMC::hmm, py::return_value_policy::reference_internal);
 
+  m.def("cmBetween", &cmBetween, "w1"_a, "w2"_a, "geneticPositions"_a, "wordSize"_a);
+  py::class_<Match>(m, "Match")
+      .def(py::init<unsigned long, int>(), "wordSize"_a = 64, "i"_a = 0)
+      .def("extend", &Match::extend)
+      .def("addGap", &Match::addGap)
+      .def("getGaps", &Match::getGaps)
+      .def("getWordSize", &Match::getWordSize)
+      .def("getInterval", [](const Match& x) { return std::vector<int>{x.start(), x.end()}; });
+  m.def("hashingCandidates",
+        [](const Data& d, const DecodingParams& p) {
+          py::list out;
+          for (const auto& c : hashingCandidates(d, p)) {
+            out.append(py::make_tuple(c.hapA, c.hapB, c.from, c.to));
+          }
+          return out;
+        },
+        "data"_a, "params"_a, "candidate (hapA, hapB, fromSite, toSite) list of the identification step");
   m.def("roundMorgans", &roundMorgans, "value"_a, "precision"_a, "min"_a);
   m.def("roundPhysical", &roundPhysical, "value"_a, "precision"_a);
   m.def("getFromPosition", &getFromPosition, "geneticPositions"_a, "from"_a, "cmDist"_a = 0.5f);

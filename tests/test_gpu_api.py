@@ -125,9 +125,18 @@ def test_decode_from_hashing_batches_windows_like_the_reference(files, small_pro
         hmm.decodeFromHashing(int(a), int(b), f, t)
     hmm.finishFromHashing()
     got = hmm.getIbdRecords()
-    sp = small_problem
-    pm, gen, folded = sp["model"], sp["gen"], sp["folded"]
-    want = []
+    recs, _ = _oracle_hashing_records(small_problem, small_problem["folded"], small_problem["model"], cands)
+    want = [(cands[int(r["pair"])][0], cands[int(r["pair"])][1], int(r["start"]), int(r["end"]), float(r["prob"]),
+             float(r["postMean"]), float(r["map"])) for r in recs]
+    assert len(want) > 10
+    assert [tuple(x) for x in got] == want
+
+
+def _oracle_hashing_records(sp, folded, pm, cands):
+    """Batches of 32 candidates in arrival order; window = union of the batch's candidate windows padded by 0.5 cM;
+    every pair scanned over the un-padded union (HMM.cpp:470-502, 555-636, 1199-1206)."""
+    gen = sp["gen"]
+    recs = []
     for b0 in range(0, len(cands), 32):
         batch = cands[b0:b0 + 32]
         start = min(c[2] for c in batch)
@@ -140,11 +149,32 @@ def test_decode_from_hashing_batches_windows_like_the_reference(files, small_pro
             hb = np.concatenate([hb, hb[-1:]])
         post, _ = O.decode_batch(pm, ob, hb, frm, to)
         for v in range(len(batch)):
-            for r in O.ibd_scan_pair(pm, post, v, start, end, pair_ordinal=b0 + v):
-                want.append((batch[v][0], batch[v][1], int(r["start"]), int(r["end"]), float(r["prob"]),
-                             float(r["postMean"]), float(r["map"])))
-    assert len(want) > 10
-    assert [tuple(x) for x in got] == want
+            recs.append(O.ibd_scan_pair(pm, post, v, start, end, pair_ordinal=b0 + v))
+    recs = np.concatenate(recs) if recs else np.zeros(0, O.IBD_DTYPE)
+    return recs, [(c[0], c[1]) for c in cands]
+
+
+@pytest.mark.parametrize("jobs,job_ind", [(1, 1), (4, 3)])
+def test_fastsmc_run_with_hashing_matches_oracle_text(files, small_problem, tmp_path, jobs, job_ind):
+    """FastSMC.run() with the identification step on (FastSMC.cpp:118-235): hashing candidates -> batched window
+    decodes -> IBD text, against the restated pre-filter (tests/test_hashing.py) + the oracle's batches."""
+    from test_hashing import restate_candidates
+
+    sp = small_problem
+    out = str(tmp_path / "hashrun")
+    p = _params(files, out, hashing=True, min_m=1.0, jobs=jobs, jobInd=job_ind)
+    api.FastSMC(p).run()
+    got = gzip.open(out + f".{job_ind}.{jobs}.FastSMC.ibd.gz", "rt").read()
+    individuals = O.job_individuals(32, jobs, job_ind) if jobs > 1 else list(range(32))
+    alleles = sp["haps"].alleles
+    cands = restate_candidates(alleles, sp["gen"], individuals, jobs=jobs, job_ind=job_ind, min_m=1.0)
+    assert len(cands) >= 20
+    rows = np.array([2 * d + h for d in individuals for h in (0, 1)])
+    recs, pairs = _oracle_hashing_records(sp, sp["folded"][rows], sp["model"], cands)
+    ids = [f"1_{d + 1}" for d in individuals]
+    want = O.format_ibd_text(recs, pairs, ids, ids, 1, sp["haps"].bp, sp["gen"])
+    assert want.count("\n") > 10
+    assert got == want
 
 
 def test_binary_output_round_trip(files, small_problem, tmp_path):
