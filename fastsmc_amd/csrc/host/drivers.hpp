@@ -41,6 +41,7 @@ public:
   FastSMC(const std::string& inFileRoot, const std::string& outFileRoot);
   void run(); // FastSMC.cpp:41-238
   HMM& hmm() { return mHmm; }
+  std::string outputFileName() const { return mHmm.ibdFileName(mParams.jobs, mParams.jobInd); }
 
 private:
   DecodingParams mParams;

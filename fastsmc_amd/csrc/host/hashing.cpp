@@ -166,7 +166,20 @@ template <typename Sink> void HashingPrefilter::run(Sink&& sink)
 void runHashing(const Data& data, const DecodingParams& params, HMM& hmm)
 {
   HashingPrefilter pf(data, params);
-  pf.run([&](const HashingCandidate& c) { hmm.decodeFromHashing(c.hapA, c.hapB, c.from, c.to); });
+  if (hmm.shardWorld() == 1) {
+    pf.run([&](const HashingCandidate& c) { hmm.decodeFromHashing(c.hapA, c.hapB, c.from, c.to); });
+    return;
+  }
+  // sharded: every rank runs the (cheap, host-side) identification step and decodes a contiguous range of the
+  // resulting batches, so each batch has the composition -- hence the window -- of a single-device run
+  std::vector<HashingCandidate> all;
+  pf.run([&](const HashingCandidate& c) { all.push_back(c); });
+  const auto B = static_cast<unsigned long long>(hmm.batchSize());
+  const auto [lo, hi] = hmm.shardBatchRange((all.size() + B - 1) / B);
+  const size_t first = std::min<size_t>(all.size(), lo * B), last = std::min<size_t>(all.size(), hi * B);
+  for (size_t i = first; i < last; ++i) {
+    hmm.decodeFromHashing(all[i].hapA, all[i].hapB, all[i].from, all[i].to);
+  }
 }
 
 std::vector<HashingCandidate> hashingCandidates(const Data& data, const DecodingParams& params)

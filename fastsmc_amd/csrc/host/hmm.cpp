@@ -612,22 +612,43 @@ void HMM::flush()
   mBatchBegin = 0;
 }
 
+void HMM::setShard(int rank, int world)
+{
+  if (world < 1 || rank < 0 || rank >= world) {
+    throw std::runtime_error("setShard: need 0 <= rank < world");
+  }
+  mShardRank = rank;
+  mShardWorld = world;
+}
+
+std::pair<unsigned long long, unsigned long long> HMM::shardBatchRange(unsigned long long nBatches) const
+{
+  const auto r = static_cast<unsigned long long>(mShardRank), w = static_cast<unsigned long long>(mShardWorld);
+  return {nBatches * r / w, nBatches * (r + 1) / w};
+}
+
+std::string HMM::ibdFileName(int jobs, int jobInd) const
+{
+  std::string name = mParams.outFileRoot + "." + std::to_string(jobInd) + "." + std::to_string(jobs) +
+                     (mParams.BIN_OUT ? ".FastSMC.bibd.gz" : ".FastSMC.ibd.gz");
+  if (mShardWorld > 1) {
+    name += ".part" + std::to_string(mShardRank) + "of" + std::to_string(mShardWorld);
+  }
+  return name;
+}
+
 void HMM::openIbdFile(int jobs, int jobInd)
 {
   if (mIbdFile) {
     gzclose(mIbdFile);
     mIbdFile = nullptr;
   }
-  const std::string base = mParams.outFileRoot + "." + std::to_string(jobInd) + "." + std::to_string(jobs);
-  if (!mParams.BIN_OUT) {
-    mIbdFile = gzopen((base + ".FastSMC.ibd.gz").c_str(), "w");
-  } else {
-    mIbdFile = gzopen((base + ".FastSMC.bibd.gz").c_str(), "wb");
-  }
+  const std::string name = ibdFileName(jobs, jobInd);
+  mIbdFile = gzopen(name.c_str(), mParams.BIN_OUT ? "wb" : "w");
   if (!mIbdFile) {
-    throw std::runtime_error("cannot open IBD output file with prefix " + base);
+    throw std::runtime_error("cannot open IBD output file " + name);
   }
-  if (mParams.BIN_OUT) {
+  if (mParams.BIN_OUT && mShardRank == 0) {
     writeBinaryHeader();
   }
 }
@@ -646,13 +667,18 @@ void HMM::decodeAll(int jobs, int jobInd)
   const unsigned long long totPairs = mParams.withinOnly ? N : 2 * N * N - N;
   const unsigned long long pairsStart = totPairs * static_cast<unsigned long long>(jobInd - 1) / jobs;
   const unsigned long long pairsEnd = totPairs * static_cast<unsigned long long>(jobInd) / jobs;
+  // this device's share of the job: whole batches, contiguous (setShard)
+  const auto B = static_cast<unsigned long long>(mBatchSize);
+  const auto [batchLo, batchHi] = shardBatchRange((pairsEnd - pairsStart + B - 1) / B);
+  const unsigned long long shardStart = std::min(pairsEnd, pairsStart + batchLo * B);
+  const unsigned long long shardEnd = std::min(pairsEnd, pairsStart + batchHi * B);
   unsigned long long pairs = 0;
   for (unsigned i = 0; i < N; i++) {
     if (!mParams.withinOnly) {
       for (unsigned j = 0; j < i; j++) {
         for (int iHap = 1; iHap <= 2; iHap++) {
           for (int jHap = 1; jHap <= 2; jHap++) {
-            if (pairsStart <= pairs && pairs < pairsEnd) {
+            if (shardStart <= pairs && pairs < shardEnd) {
               // makePairObs(jHap, j, iHap, i): the lower-numbered individual is the record's first id
               queuePair(static_cast<unsigned>(dipToHapId(j, jHap)), static_cast<unsigned>(dipToHapId(i, iHap)));
             }
@@ -661,7 +687,7 @@ void HMM::decodeAll(int jobs, int jobInd)
         }
       }
     }
-    if (pairsStart <= pairs && pairs < pairsEnd) {
+    if (shardStart <= pairs && pairs < shardEnd) {
       queuePair(static_cast<unsigned>(dipToHapId(i, 1)), static_cast<unsigned>(dipToHapId(i, 2)));
     }
     pairs++;

@@ -109,6 +109,18 @@ public:
   void setStoreSumOfPosterior(bool v) { mStoreSumOfPosterior = v; }
   void resetDecoding(); // HMM.cpp:258-280
 
+  // Multi-GPU: this process decodes shard `rank` of `world` -- a contiguous range of the job's batches (whole
+  // batches, so batch windows are those of a single-device run).  Output goes to "<file>.part<rank>of<world>";
+  // parts concatenated in rank order are byte-for-byte a valid gzip stream of the single-device content
+  // (only rank 0 writes the binary header).  Call before decodeAll.
+  void setShard(int rank, int world);
+  int shardRank() const { return mShardRank; }
+  int shardWorld() const { return mShardWorld; }
+  // [first, last) batch ordinals of this shard out of nBatches
+  std::pair<unsigned long long, unsigned long long> shardBatchRange(unsigned long long nBatches) const;
+  std::string ibdFileName(int jobs, int jobInd) const;
+  int batchSize() const { return mBatchSize; }
+
   // keep emitted IBD records in memory as well (tests, benchmarks)
   void setKeepIbdRecords(bool v) { mKeepRecords = v; }
   const std::vector<fsmc_ibd_record>& getIbdRecords() const { return mKeptRecords; }
@@ -149,6 +161,7 @@ private:
   std::vector<unsigned> mFromBatch, mToBatch; // per slot of the open batch (hashing mode), HMM.cpp:491-493
   unsigned long mHashingCount = 0;            // "cpt"
   size_t mFlushThreshold = 1u << 20;
+  int mShardRank = 0, mShardWorld = 1;
 
   // outputs
   gzFile mIbdFile = nullptr;

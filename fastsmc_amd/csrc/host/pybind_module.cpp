@@ -328,6 +328,9 @@ PYBIND11_MODULE(_pyasmc, m)
       .def("decodeHapPair", &HMM::decodeHapPair)
       .def("decodeHapPairs", &HMM::decodeHapPairs)
       .def("decodeFromHashing", &HMM::decodeFromHashing, "hapA"_a, "hapB"_a, "fromPosition"_a, "toPosition"_a)
+      .def("setShard", &HMM::setShard, "rank"_a, "world"_a,
+           "decode only shard `rank` of `world` (contiguous whole batches) and write <file>.part<rank>of<world>")
+      .def("ibdFileName", &HMM::ibdFileName, "jobs"_a, "jobInd"_a)
       .def("getBatchBuffer", [](const HMM& h) { return std::vector<int>(h.getQueuedPairs(), 0); },
            "one entry per queued pair (the reference returns its vector of queued PairObservations)")
       .def("finishDecoding", &HMM::finishDecoding)
@@ -385,6 +388,8 @@ PYBIND11_MODULE(_pyasmc, m)
       .def(py::init<DecodingParams>(), "decodingParams"_a)
       .def(py::init<const std::string&, const std::string&>(), "in_dir"_a, "out_dir"_a)
       .def("run", &FastSMC::run)
+      .def("setShard", [](FastSMC& f, int rank, int world) { f.hmm().setShard(rank, world); }, "rank"_a, "world"_a)
+      .def("outputFileName", &FastSMC::outputFileName)
       .def("hmm", &FastSMC::hmm, py::return_value_policy::reference_internal);
 
   py::class_<ASMC>(m, "ASMC")

@@ -43,3 +43,48 @@ def gather_ibd_records(rec: np.ndarray, pair_offset: int, dist, rank: int, world
     out = np.concatenate(parts) if parts else local[:0]
     # shards are contiguous and each is already ordered, so concatenation is the single-device order
     return sum(counts), out
+
+
+def run_fastsmc_sharded(params, rank: int | None = None, world: int | None = None, local_rank: int | None = None,
+                        barrier=None) -> str | None:
+    """FastSMC.run() of one job spread over ``world`` GPUs, one process each (launch with
+    ``python -m torch.distributed.run --nproc-per-node N ...`` or pass rank/world explicitly).  Every rank loads
+    the same inputs, decodes a contiguous range of the job's batches on device ``local_rank`` and writes
+    ``<output>.part<rank>of<world>``; after a barrier rank 0 concatenates the parts in rank order -- gzip members
+    concatenate into a valid stream whose content is byte-identical to the single-GPU output -- and removes them.
+    No collective on the data path.  Returns the output file name on rank 0, None elsewhere."""
+    import os
+    import shutil
+
+    from . import api
+
+    rank = int(os.environ.get("RANK", 0)) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
+    local_rank = int(os.environ.get("LOCAL_RANK", rank)) if local_rank is None else local_rank
+    if barrier is None and world > 1:
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only
+        barrier = dist.barrier
+    params.gpuDevice = local_rank
+    f = api.FastSMC(params)
+    f.setShard(rank, world)
+    part = f.outputFileName()
+    f.run()
+    if world == 1:
+        return part
+    barrier()
+    final = None
+    if rank == 0:
+        final = part[: part.rindex(".part")]
+        with open(final, "wb") as out:
+            for r in range(world):
+                name = f"{final}.part{r}of{world}"
+                with open(name, "rb") as src:
+                    shutil.copyfileobj(src, out)
+                os.remove(name)
+    barrier()
+    return final

@@ -1,0 +1,60 @@
+"""Multi-GPU product path (scope row e): one job sharded over `world` processes, each decoding a contiguous range
+of whole batches; the concatenated part files must decompress to exactly the single-device output -- text and
+binary, all-pairs and hashing mode.  The GPU box has one device, so all ranks use device 0."""
+import gzip
+import multiprocessing as mp
+import os
+import socket
+
+import pytest
+
+from fastsmc_amd import api, dist
+from test_gpu_api import _params, files  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(files, out, **kw):
+    p = _params(files, out, **kw)
+    f = api.FastSMC(p)
+    f.run()
+    return gzip.open(f.outputFileName(), "rb").read()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(BIN_OUT=True), dict(hashing=True, min_m=1.0),
+                                dict(jobs=9, jobInd=7)], ids=["text", "binary", "hashing", "job7of9"])
+def test_sharded_in_process_equals_single_device(files, tmp_path, kw):
+    want = _single(files, str(tmp_path / "one"), **kw)
+    assert len(want) > 1000
+    world = 3
+    final = None
+    for rank in (1, 2, 0):  # rank 0 last: it concatenates the parts
+        p = _params(files, str(tmp_path / "sharded"), **kw)
+        r = dist.run_fastsmc_sharded(p, rank=rank, world=world, local_rank=0, barrier=lambda: None)
+        final = r or final
+    assert final and not final.endswith(f"of{world}")
+    assert gzip.open(final, "rb").read() == want
+    assert not [n for n in os.listdir(tmp_path) if ".part" in n]
+
+
+def _worker(rank, world, port, files, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    p = _params(files, out, hashing=True, min_m=1.0)
+    dist.run_fastsmc_sharded(p, rank=rank, world=world, local_rank=0)
+
+
+def test_sharded_two_processes(files, tmp_path):
+    want = _single(files, str(tmp_path / "one"), hashing=True, min_m=1.0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "two")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, files, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+        assert pr.exitcode == 0
+    assert gzip.open(out + ".1.1.FastSMC.ibd.gz", "rb").read() == want

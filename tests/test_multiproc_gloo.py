@@ -64,3 +64,15 @@ def test_record_gather_world_size_2(tmp_path):
     want = np.concatenate(want)
     assert merged.dtype == want.dtype and np.array_equal(merged, want)
     assert np.all(np.diff(merged["pair"].astype(np.int64)) >= 0)  # single-device output order
+
+
+def test_shard_batch_ranges_tile_the_job():
+    """HMM.setShard's rule (whole batches, contiguous, nBatches*r/R) restated: shards tile the batch list."""
+    from fastsmc_amd.dist import shard_pair_range
+
+    for n_pairs in (0, 1, 31, 32, 33, 2016, 499500):
+        for world in (1, 2, 3, 8):
+            edges = [shard_pair_range(n_pairs, r, world, batch=32) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n_pairs
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            assert all(lo % 32 == 0 for lo, _ in edges)
