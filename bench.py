@@ -112,6 +112,8 @@ def main() -> None:
     ap.add_argument("--haps", type=int, default=1000)
     ap.add_argument("--sites", type=int, default=50000)
     ap.add_argument("--states", type=int, default=69)
+    ap.add_argument("--chunk-sites", type=int, default=0, help="sites between beta checkpoints (0 = automatic)")
+    ap.add_argument("--ws-frac", type=float, default=0.0, help="workspace cap as a fraction of HBM (0 = default)")
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs in the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -140,6 +142,10 @@ def main() -> None:
     model = ctx.create_model(pm)
     ctx.upload_haps(bits, pm.S)
     ctx.upload_worklist(pairs.view(capi.PAIR_DTYPE).reshape(-1), groups)
+    if args.chunk_sites:
+        ctx.set_chunk_sites(args.chunk_sites)
+    if args.ws_frac:
+        ctx.set_workspace_limit(int(args.ws_frac * ctx.info()["hbm_bytes"]))
     flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
 
     from fastsmc_amd.dist import gather_ibd_records
@@ -193,6 +199,7 @@ def main() -> None:
                                    f"{n_pairs} pairs per GPU, FastSMC-mode IBD + posterior-mean/MAP ages, no hashing",
                        "pair_sites_per_s": value * pm.S, "ibd_records_per_step": n_rec,
                        "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
+                       "chunk_sites": info["chunk_sites"], "chunks_per_window": info["max_chunks"],
                        **({"phase_cycles": [int(x) for x in phase]} if phase.any() else {})},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": measured_traffic(args.haps, args.sites, pm.K),

@@ -26,6 +26,7 @@ FSMC_EOVERFLOW = -6
 # every symbol include/fastsmc_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
+    "fsmc_ctx_set_chunk_sites", "fsmc_ctx_last_plan",
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
     "fsmc_decode_ibd",
@@ -76,6 +77,8 @@ def load():
         L.fsmc_last_error.restype = C.c_char_p
         L.fsmc_ctx_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]
         L.fsmc_ctx_set_workspace_limit.argtypes = [vp, u64]
+        L.fsmc_ctx_set_chunk_sites.argtypes = [vp, u32]
+        L.fsmc_ctx_last_plan.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.fsmc_model_create.argtypes = [vp, C.POINTER(_ModelDesc), C.POINTER(vp)]
         L.fsmc_model_destroy.argtypes = [vp]
         L.fsmc_model_destroy.restype = None
@@ -145,7 +148,13 @@ class Context:
     def info(self) -> dict:
         cu, slots, hbm = C.c_int32(), C.c_int32(), C.c_uint64()
         self._check(self._L.fsmc_ctx_info(self._h, C.byref(cu), C.byref(slots), C.byref(hbm)))
-        return {"n_cu": cu.value, "n_slots": slots.value, "hbm_bytes": hbm.value}
+        chunk, chunks = C.c_int32(), C.c_int32()
+        self._check(self._L.fsmc_ctx_last_plan(self._h, C.byref(chunk), C.byref(chunks), None))
+        return {"n_cu": cu.value, "n_slots": slots.value, "hbm_bytes": hbm.value, "chunk_sites": chunk.value,
+                "max_chunks": chunks.value}
+
+    def set_chunk_sites(self, sites: int):
+        self._check(self._L.fsmc_ctx_set_chunk_sites(self._h, sites))
 
     def set_workspace_limit(self, nbytes: int):
         self._check(self._L.fsmc_ctx_set_workspace_limit(self._h, nbytes))

@@ -58,6 +58,8 @@ struct fsmc_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int lastSlots = 0;
+  int lastChunk = 0, lastMaxChunks = 0;
+  uint32_t chunkSites = 0; // 0 = automatic
 
   const fsmc_model* ibdModel = nullptr;
   uint32_t ibdFlags = 0;
@@ -210,8 +212,8 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     C = L;
     maxChunks = 1;
   } else {
-    C = (size_t)std::ceil(std::sqrt((double)L));
-    C = (C + 15) / 16 * 16;
+    C = ctx->chunkSites ? (size_t)ctx->chunkSites : (size_t)std::ceil(std::sqrt((double)L));
+    C = std::min((C + 15) / 16 * 16, (L + 15) / 16 * 16);
     maxChunks = (L + C - 1) / C;
     if ((C + maxChunks + 5) * vecBytes * slots > limit) {
       return fail(ctx, FSMC_ENOMEM, "workspace limit too small for the decode window");
@@ -221,6 +223,8 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   plan.maxChunks = (int)maxChunks;
   plan.wsSlot = (C + maxChunks + 2 + 2) * K4 * kWave;
   plan.slots = (int)slots;
+  ctx->lastChunk = plan.chunk;
+  ctx->lastMaxChunks = plan.maxChunks;
   return ensure(ctx, ctx->ws, plan.wsSlot * sizeof(float4) * slots);
 }
 
@@ -415,6 +419,26 @@ int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes)
     return FSMC_EINVAL;
   }
   ctx->wsLimit = bytes;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites)
+{
+  if (!ctx) {
+    return FSMC_EINVAL;
+  }
+  ctx->chunkSites = sites;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_chunks, int32_t* n_slots)
+{
+  if (!ctx) {
+    return FSMC_EINVAL;
+  }
+  if (chunk_sites) *chunk_sites = ctx->lastChunk;
+  if (max_chunks) *max_chunks = ctx->lastMaxChunks;
+  if (n_slots) *n_slots = ctx->lastSlots;
   return FSMC_OK;
 }
 

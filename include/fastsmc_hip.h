@@ -108,6 +108,12 @@ const char* fsmc_last_error(const fsmc_ctx* ctx);
 int fsmc_ctx_info(const fsmc_ctx* ctx, int32_t* n_cu, int32_t* n_slots, uint64_t* hbm_bytes);
 /* Cap on the workspace the library may allocate for alpha/beta streaming (bytes; 0 = default 40 % of HBM). */
 int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes);
+/* Tuning: sites between beta checkpoints when a decode window does not fit the workspace (0 = automatic,
+ * ceil(sqrt(window)) rounded up to 16).  Results do not depend on it. */
+int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites);
+/* How the last launch was laid out: sites per chunk (= the longest window when every beta row fitted), chunks per
+ * window, resident waves. */
+int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_chunks, int32_t* n_slots);
 
 /* ---- resident inputs ---- */
 int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* desc, fsmc_model** out);
