@@ -22,7 +22,9 @@ def decoding_quantities_from_tables(t) -> DecodingQuantities:
     """Wrap a ``fastsmc_amd.synth.ModelTables`` as a ``DecodingQuantities`` without going through a file."""
     return DecodingQuantities.from_arrays(
         int(t.csfs_samples), t.discretization, t.expected_times, t.initial_state_prob, t.column_ratios, t.keys,
-        t.D, t.B, t.U, t.RR, t.compressed_emission, t.classic_emission, t.folded_ascertained_csfs, t.ascertained_csfs)
+        t.D, t.B, t.U, t.RR, t.compressed_emission, t.classic_emission, t.folded_ascertained_csfs, t.ascertained_csfs,
+        t.csfs, t.folded_csfs, t.homozygous_keys if t.homozygous_keys.size else None,
+        t.homozygous if t.homozygous_keys.size else None)
 
 
 class PreparedModelView:

@@ -55,6 +55,9 @@ class _ModelDesc(C.Structure):
         ("step_row", C.c_void_p),
         ("e1", C.c_void_p), ("e0m1", C.c_void_p), ("e2m0", C.c_void_p),
         ("state_threshold", C.c_uint32), ("age_threshold", C.c_uint32), ("probability_threshold", C.c_float),
+        ("sequence", C.c_int32),
+        ("gap_row_f", C.c_void_p), ("site_row_f", C.c_void_p), ("gap_row_b", C.c_void_p), ("site_row_b", C.c_void_p),
+        ("hom", C.c_void_p),
     ]
 
 
@@ -256,6 +259,14 @@ class Model:
         d.state_threshold = int(pm.state_threshold)
         d.age_threshold = int(pm.age_threshold)
         d.probability_threshold = float(pm.probability_threshold)
+        if getattr(pm, "sequence", False):  # decodingSequence: two steps per site (fsmc_model_desc)
+            i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+            keep.update(gf=i32(pm.gap_row_f), sf=i32(pm.site_row_f), gb=i32(pm.gap_row_b), sb=i32(pm.site_row_b),
+                        hom=f32(pm.hom))
+            d.sequence = 1
+            d.gap_row_f, d.site_row_f = _p(keep["gf"]), _p(keep["sf"])
+            d.gap_row_b, d.site_row_b = _p(keep["gb"]), _p(keep["sb"])
+            d.hom = _p(keep["hom"])
         h = C.c_void_p()
         ctx._check(ctx._L.fsmc_model_create(ctx._h, C.byref(d), C.byref(h)))
         self._h = h

@@ -207,10 +207,6 @@ void HMM::init(int scalingSkip)
     // every caller in the reference uses 1 (HMM.hpp:172, pybind.cpp:219); the GPU path rescales every site
     throw std::runtime_error("scalingSkip != 1 is not supported");
   }
-  if (mParams.decodingSequence) {
-    throw std::runtime_error("sequence mode (two-step transition with homozygous emissions) is outside this "
-                             "build's hot-path scope; use array mode");
-  }
   if (mParams.noBatches) {
     // the reference's noBatches runs its scalar debugging path; here every decode is batched on the GPU
     mParams.noBatches = false;
@@ -243,7 +239,8 @@ HMM::~HMM()
 
 void HMM::prepareEmissions()
 {
-  // HMM.cpp:159-256, array mode (decodingSequence == false)
+  // HMM.cpp:159-256
+  const bool seq = mParams.decodingSequence;
   const int S = mData.sites;
   const int K = static_cast<int>(mDq.states);
   const auto undist = mData.calculateUndistinguishedCounts(mDq.CSFSSamples);
@@ -276,7 +273,7 @@ void HMM::prepareEmissions()
     if (mUseCSFS[pos]) {
       const int u0 = undist[pos][0], u1 = undist[pos][1], u2 = undist[pos][2];
       if (mParams.foldData) {
-        const auto& map = mDq.foldedAscertainedCSFSmap;
+        const auto& map = seq ? mDq.foldedCSFSmap : mDq.foldedAscertainedCSFSmap;
         const float* r1 = u1 >= 0 ? csfsRow(map, u1, 1) : nullptr;
         const float* r0 = csfsRow(map, u0, 0);
         const float* r2 = u2 >= 0 ? csfsRow(map, u2, 0) : nullptr;
@@ -286,7 +283,7 @@ void HMM::prepareEmissions()
           e2m0[k] = r2 ? (r2[k] - r0[k]) : (0 - r0[k]);
         }
       } else {
-        const auto& map = mDq.ascertainedCSFSmap;
+        const auto& map = seq ? mDq.CSFSmap : mDq.ascertainedCSFSmap;
         const float* r1 = u1 >= 0 ? csfsRow(map, u1, 1) : nullptr;
         const float* r0 = u0 >= 0 ? csfsRow(map, u0, 0) : nullptr;
         const float* r2 = nullptr;
@@ -302,11 +299,13 @@ void HMM::prepareEmissions()
         }
       }
     } else {
-      if (mDq.compressedEmissionTable.size() != 2) {
-        throw std::runtime_error("decoding quantities lack the CompressedAscertainedEmission table");
+      const auto& table = seq ? mDq.classicEmissionTable : mDq.compressedEmissionTable;
+      if (table.size() != 2) {
+        throw std::runtime_error(seq ? "decoding quantities lack the ClassicEmission table"
+                                     : "decoding quantities lack the CompressedAscertainedEmission table");
       }
-      const float* c0 = mDq.compressedEmissionTable[0].data();
-      const float* c1 = mDq.compressedEmissionTable[1].data();
+      const float* c0 = table[0].data();
+      const float* c1 = table[1].data();
       for (int k = 0; k < K; k++) {
         e1[k] = c1[k];
         e0m1[k] = c0[k] - c1[k];
@@ -342,14 +341,45 @@ void HMM::prepareModel()
   mPrep.stepRow.assign(static_cast<size_t>(S), 0);
   std::map<uint32_t, int> rowOfKey;
   std::vector<float> keys;
-  for (int p = 1; p < S; ++p) {
-    const float key = roundMorgans(mData.geneticPositions[p] - mData.geneticPositions[p - 1], precision, minGenetic);
+  auto rowFor = [&](float key) {
     auto it = rowOfKey.find(floatBits(key));
     if (it == rowOfKey.end()) {
       it = rowOfKey.emplace(floatBits(key), static_cast<int>(keys.size())).first;
       keys.push_back(key);
     }
-    mPrep.stepRow[p] = it->second;
+    return it->second;
+  };
+  mPrep.sequence = mParams.decodingSequence;
+  if (mPrep.sequence) {
+    mPrep.gapRowF.assign(static_cast<size_t>(S), 0);
+    mPrep.siteRowF.assign(static_cast<size_t>(S), 0);
+    mPrep.gapRowB.assign(static_cast<size_t>(S), 0);
+    mPrep.siteRowB.assign(static_cast<size_t>(S), 0);
+    mPrep.hom.assign(static_cast<size_t>(S) * K, 0.f);
+    if (static_cast<int>(mData.recRateAtMarker.size()) != S || static_cast<int>(mData.physicalPositions.size()) != S) {
+      throw std::runtime_error("sequence mode needs recombination rates and physical positions for every site");
+    }
+  }
+  for (int p = 1; p < S; ++p) {
+    const float key = roundMorgans(mData.geneticPositions[p] - mData.geneticPositions[p - 1], precision, minGenetic);
+    mPrep.stepRow[p] = rowFor(key);
+    if (mPrep.sequence) {
+      // forward into site p (HMM.cpp:755-770): the rate of site p; backward out of site p, i.e. the step that
+      // computes beta of p-1 (HMM.cpp:909-925): the rate of site p-1
+      const float rateHere = roundMorgans(mData.recRateAtMarker[p], precision, minGenetic);
+      const float ratePrev = roundMorgans(mData.recRateAtMarker[p - 1], precision, minGenetic);
+      mPrep.gapRowF[p] = rowFor(roundMorgans(key - rateHere, precision, minGenetic));
+      mPrep.siteRowF[p] = rowFor(rateHere);
+      mPrep.gapRowB[p] = rowFor(roundMorgans(key - ratePrev, precision, minGenetic));
+      mPrep.siteRowB[p] = rowFor(ratePrev);
+      const int physKey = roundPhysical(mData.physicalPositions[p] - mData.physicalPositions[p - 1] - 1, precision);
+      const auto it = mDq.homozygousEmissionMap.find(physKey);
+      if (it == mDq.homozygousEmissionMap.end() || static_cast<int>(it->second.size()) != K) {
+        // the reference throws std::out_of_range from unordered_map::at
+        throw std::out_of_range("no HomozygousEmissions entry for physical distance " + std::to_string(physKey));
+      }
+      std::copy(it->second.begin(), it->second.end(), mPrep.hom.begin() + static_cast<size_t>(p) * K);
+    }
   }
   if (keys.empty()) {
     keys.push_back(minGenetic);
@@ -427,6 +457,14 @@ void HMM::ensureEngine()
     d.state_threshold = mPrep.stateThreshold;
     d.age_threshold = mPrep.ageThreshold;
     d.probability_threshold = mPrep.probabilityThreshold;
+    if (mPrep.sequence) {
+      d.sequence = 1;
+      d.gap_row_f = mPrep.gapRowF.data();
+      d.site_row_f = mPrep.siteRowF.data();
+      d.gap_row_b = mPrep.gapRowB.data();
+      d.site_row_b = mPrep.siteRowB.data();
+      d.hom = mPrep.hom.data();
+    }
     check(mCtx, fsmc_model_create(mCtx, &d, &mModel), "fsmc_model_create");
   }
   if (!mHapsUploaded) {

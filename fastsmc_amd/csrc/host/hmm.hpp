@@ -67,6 +67,10 @@ struct PreparedModel {
   std::vector<float> e1, e0m1, e2m0;   // [S][K]
   unsigned stateThreshold = 0, ageThreshold = 0;
   float probabilityThreshold = 0.f;
+  // sequence mode (HMM.cpp:760-770, 915-925): see fsmc_model_desc
+  bool sequence = false;
+  std::vector<int32_t> gapRowF, siteRowF, gapRowB, siteRowB; // [S]
+  std::vector<float> hom;                                    // [S][K]
 };
 
 class HMM

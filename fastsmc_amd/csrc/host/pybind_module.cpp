@@ -148,7 +148,8 @@ PYBIND11_MODULE(_pyasmc, m)
              py::array_t<float, py::array::c_style | py::array::forcecast> compressedEmission,
              py::array_t<float, py::array::c_style | py::array::forcecast> classicEmission,
              py::array_t<float, py::array::c_style | py::array::forcecast> foldedAscertainedCSFS,
-             py::array_t<float, py::array::c_style | py::array::forcecast> ascertainedCSFS) {
+             py::array_t<float, py::array::c_style | py::array::forcecast> ascertainedCSFS,
+             py::object CSFS, py::object foldedCSFS, py::object homozygousKeys, py::object homozygousEmissions) {
             DecodingQuantities q;
             q.states = static_cast<unsigned>(expectedTimes.size());
             q.CSFSSamples = csfsSamples;
@@ -174,11 +175,29 @@ PYBIND11_MODULE(_pyasmc, m)
             q.classicEmissionTable = asMat(classicEmission);
             q.foldedAscertainedCSFSmap = asCube(foldedAscertainedCSFS);
             q.ascertainedCSFSmap = asCube(ascertainedCSFS);
+            using FArr = py::array_t<float, py::array::c_style | py::array::forcecast>;
+            if (!CSFS.is_none()) {
+              q.CSFSmap = asCube(CSFS.cast<FArr>());
+            }
+            if (!foldedCSFS.is_none()) {
+              q.foldedCSFSmap = asCube(foldedCSFS.cast<FArr>());
+            }
+            if (!homozygousKeys.is_none() && !homozygousEmissions.is_none()) {
+              const auto hk = homozygousKeys.cast<py::array_t<int32_t, py::array::c_style | py::array::forcecast>>();
+              const auto hv = homozygousEmissions.cast<FArr>();
+              if (hv.ndim() != 2 || hv.shape(0) != hk.size() || hv.shape(1) != static_cast<py::ssize_t>(q.states)) {
+                throw std::runtime_error("homozygous emissions must be [keys][states]");
+              }
+              for (py::ssize_t r = 0; r < hk.size(); ++r) {
+                q.homozygousEmissionMap[hk.at(r)] = std::vector<float>(hv.data(r, 0), hv.data(r, 0) + q.states);
+              }
+            }
             return q;
           },
           "CSFSSamples"_a, "discretization"_a, "expectedTimes"_a, "initialStateProb"_a, "columnRatios"_a, "keys"_a,
           "D"_a, "B"_a, "U"_a, "RR"_a, "compressedEmissionTable"_a, "classicEmissionTable"_a,
-          "foldedAscertainedCSFSmap"_a, "ascertainedCSFSmap"_a,
+          "foldedAscertainedCSFSmap"_a, "ascertainedCSFSmap"_a, "CSFSmap"_a = py::none(),
+          "foldedCSFSmap"_a = py::none(), "homozygousKeys"_a = py::none(), "homozygousEmissions"_a = py::none(),
           "Build decoding quantities from arrays instead of a file (synthetic models).")
       .def_readwrite("CSFSSamples", &DecodingQuantities::CSFSSamples)
       .def_readwrite("states", &DecodingQuantities::states)
@@ -381,6 +400,14 @@ PYBIND11_MODULE(_pyasmc, m)
         d["state_threshold"] = pm.stateThreshold;
         d["age_threshold"] = pm.ageThreshold;
         d["probability_threshold"] = pm.probabilityThreshold;
+        d["sequence"] = pm.sequence;
+        if (pm.sequence) {
+          d["gap_row_f"] = toArray<int32_t>(pm.gapRowF, {S});
+          d["site_row_f"] = toArray<int32_t>(pm.siteRowF, {S});
+          d["gap_row_b"] = toArray<int32_t>(pm.gapRowB, {S});
+          d["site_row_b"] = toArray<int32_t>(pm.siteRowB, {S});
+          d["hom"] = toArray<float>(pm.hom, {S, K});
+        }
         return d;
       });
 

@@ -75,6 +75,21 @@ class ModelTables:
     csfs: np.ndarray  # [n-1][3][K]
     folded_csfs: np.ndarray  # [n-1][2][K]
     time_vector: np.ndarray = field(default_factory=lambda: np.zeros(1, np.float32))
+    # sequence mode: emission of a run of d homozygous bases, keyed by roundPhysical(d) (HMM.cpp:762-765)
+    homozygous_keys: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))  # [H] int32
+    homozygous: np.ndarray = field(default_factory=lambda: np.zeros((0, 0), np.float32))  # [H][K]
+
+
+def physical_distance_keys(max_bp: int = 2_000_000) -> np.ndarray:
+    """Every value asmc::roundPhysical(d, 2) can return for d <= max_bp (HmmUtils.cpp:81-94): 3 significant
+    digits, i.e. 1..999, then multiples of 10 up to 9990, of 100 up to 99900, ..."""
+    keys = list(range(1, 1000))
+    factor = 10
+    while keys[-1] < max_bp:
+        keys += [m * factor for m in range(100, 1000)]
+        factor *= 10
+    keys.append(1000 * (factor // 10))
+    return np.array(sorted(set(k for k in keys if k <= max(max_bp, 1000))), np.int32)
 
 
 def make_model_tables(K: int = 69, N: float = 15000.0, mu: float = 1.0e-5, csfs_samples: int = 50,
@@ -148,13 +163,16 @@ def make_model_tables(K: int = 69, N: float = 15000.0, mu: float = 1.0e-5, csfs_
         asc[u, 2] = (1.0 - het) * 0.25 * w + 1e-6
         csfs[u] = asc[u] * (0.9 + 0.1 * w)
     fcsfs = fac * 0.97
+    hkeys = physical_distance_keys()
+    mu_bp = 1.65e-8  # per-base rate for the homozygous stretches between sequence sites
+    hom = np.exp(-2.0 * mu_bp * hkeys[:, None].astype(np.float64) * s[None, :])
     f32 = lambda x: np.ascontiguousarray(x, dtype=np.float32)  # noqa: E731
     return ModelTables(
         K=K, csfs_samples=n, discretization=f32(d), expected_times=f32(s), initial_state_prob=f32(h),
         column_ratios=f32(col), keys=f32(keys), D=f32(D), B=f32(Bv), U=f32(U), RR=f32(RR),
         classic_emission=f32(classic), compressed_emission=f32(classic * np.array([[0.98], [1.0]]) + 1e-6),
         folded_ascertained_csfs=f32(fac), ascertained_csfs=f32(asc), csfs=f32(csfs), folded_csfs=f32(fcsfs),
-        time_vector=f32(np.array([0.0])),
+        time_vector=f32(np.array([0.0])), homozygous_keys=hkeys, homozygous=f32(hom),
     )
 
 
@@ -188,6 +206,11 @@ def write_decoding_quantities(path: str, t: ModelTables) -> None:
                     + "\n".join(_fmt_row(t.folded_ascertained_csfs[u, d]) for d in range(2)) + "\n")
         f.write("\nCompressedAscertainedEmission\n"
                 + "\n".join(_fmt_row(t.compressed_emission[d]) for d in range(2)) + "\n\n")
+        if t.homozygous_keys.size:
+            f.write("HomozygousEmissions\n")
+            for i, key in enumerate(t.homozygous_keys):
+                f.write(f"{int(key)}\t" + _fmt_row(t.homozygous[i]) + "\n")
+            f.write("\n")
         f.write("initialStateProb\n" + _fmt_row(t.initial_state_prob) + "\n\n")
         f.write("ColumnRatios\n" + _fmt_row(t.column_ratios[: K - 1]) + "\n\n")
         for name, tab, ncol in (("RowRatios", t.RR, K - 1), ("Uvectors", t.U, K - 1), ("Bvectors", t.B, K - 1),

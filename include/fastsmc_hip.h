@@ -65,6 +65,20 @@ typedef struct {
   uint32_t state_threshold; /* HMM::stateThreshold      (HMM.cpp:504-513) */
   uint32_t age_threshold;   /* HMM::ageThreshold        (HMM.cpp:101-105) */
   float probability_threshold; /* HMM::probabilityThreshold (HMM.cpp:96-99) */
+  /* Sequence mode (DecodingParams::decodingSequence; HMM.cpp:760-770 forward, 915-925 backward): two transition
+   * steps per site -- across the homozygous stretch since the previous site, then the site itself.  All zero /
+   * NULL in array mode (step_row is then the only row index).  Arrays are [S], indexed by the later site q of
+   * the gap (q-1, q); entry 0 unused:
+   *   gap_row_f[q]  row of key roundMorgans(recDist_q - rate[q]),   site_row_f[q]  row of key rate[q]
+   *   gap_row_b[q]  row of key roundMorgans(recDist_q - rate[q-1]), site_row_b[q]  row of key rate[q-1]
+   * (recDist_q = roundMorgans(gen[q]-gen[q-1]), rate[p] = roundMorgans(recRateAtMarker[p])), and
+   *   hom[q][K] = homozygousEmissionMap[roundPhysical(phys[q]-phys[q-1]-1)]. */
+  int32_t sequence;
+  const int32_t* gap_row_f;
+  const int32_t* site_row_f;
+  const int32_t* gap_row_b;
+  const int32_t* site_row_b;
+  const float* hom;
 } fsmc_model_desc;
 
 /* One haplotype pair: rows of the uploaded bit matrix.  Row 2*ind + (hap-1). */

@@ -218,7 +218,7 @@ void fo_decode_batch(const fo_model* m, const uint8_t* obsBits, const uint8_t* h
   float* isZero = scal + B;
   float* isTwo = isZero + B;
 
-  /* ---- forward (HMM.cpp:725-784), array mode (decodingSequence == false) ---- */
+  /* ---- forward (HMM.cpp:725-784) ---- */
   expand_obs(obsBits, homMinorBits, B, len, 0, isZero, isTwo);
   {
     float* a0 = alpha + (size_t)from * KB;
@@ -234,12 +234,22 @@ void fo_decode_batch(const fo_model* m, const uint8_t* obsBits, const uint8_t* h
     fo_calculate_scaling_batch(a0, scal, sums, B, K);
     fo_apply_scaling_batch(a0, scal, B, K);
   }
+  float* zeros = (float*)calloc((size_t)B, sizeof(float)); /* m_allZeros */
   for (unsigned pos = from + 1; pos < to; ++pos) {
     expand_obs(obsBits, homMinorBits, B, len, pos - from, isZero, isTwo);
     float* prev = alpha + (size_t)(pos - 1) * KB;
     float* next = alpha + (size_t)pos * KB;
-    next_alpha(m, m->stepRow[pos], B, prev, next, alphaC, AU, isZero, isTwo, m->e1 + (size_t)pos * K,
-               m->e0m1 + (size_t)pos * K, m->e2m0 + (size_t)pos * K);
+    if (m->sequence) {
+      /* HMM.cpp:760-770: homozygous stretch between the sites, then the site itself */
+      const float* h = m->hom + (size_t)pos * K;
+      next_alpha(m, m->gapRowF[pos], B, prev, next, alphaC, AU, zeros, zeros, h, h, h);
+      memcpy(prev, next, KB * sizeof(float)); /* previousAlpha = nextAlpha (Eigen::Map assignment copies) */
+      next_alpha(m, m->siteRowF[pos], B, prev, next, alphaC, AU, isZero, isTwo, m->e1 + (size_t)pos * K,
+                 m->e0m1 + (size_t)pos * K, m->e2m0 + (size_t)pos * K);
+    } else {
+      next_alpha(m, m->stepRow[pos], B, prev, next, alphaC, AU, isZero, isTwo, m->e1 + (size_t)pos * K,
+                 m->e0m1 + (size_t)pos * K, m->e2m0 + (size_t)pos * K);
+    }
     /* scalingSkip == 1: every site (HMM.cpp:776-779) */
     fo_calculate_scaling_batch(next, scal, sums, B, K);
     fo_apply_scaling_batch(next, scal, B, K);
@@ -261,12 +271,22 @@ void fo_decode_batch(const fo_model* m, const uint8_t* obsBits, const uint8_t* h
     /* emission and observation of site pos+1; transition key of the step pos -> pos+1 (909, 927-929) */
     expand_obs(obsBits, homMinorBits, B, len, (unsigned)(pos + 1) - from, isZero, isTwo);
     float* cur = beta + (size_t)pos * KB;
-    const float* last = beta + (size_t)(pos + 1) * KB;
-    previous_beta(m, m->stepRow[pos + 1], B, last, cur, vecBuf, BU, AU /* as BL */, isZero, isTwo,
-                  m->e1 + (size_t)(pos + 1) * K, m->e0m1 + (size_t)(pos + 1) * K, m->e2m0 + (size_t)(pos + 1) * K);
+    float* last = beta + (size_t)(pos + 1) * KB;
+    if (m->sequence) {
+      /* HMM.cpp:915-925 */
+      const float* h = m->hom + (size_t)(pos + 1) * K;
+      previous_beta(m, m->gapRowB[pos + 1], B, last, cur, vecBuf, BU, AU /* as BL */, zeros, zeros, h, h, h);
+      memcpy(last, cur, KB * sizeof(float)); /* lastComputedBeta = previousBeta */
+      previous_beta(m, m->siteRowB[pos + 1], B, last, cur, vecBuf, BU, AU, isZero, isTwo,
+                    m->e1 + (size_t)(pos + 1) * K, m->e0m1 + (size_t)(pos + 1) * K, m->e2m0 + (size_t)(pos + 1) * K);
+    } else {
+      previous_beta(m, m->stepRow[pos + 1], B, last, cur, vecBuf, BU, AU /* as BL */, isZero, isTwo,
+                    m->e1 + (size_t)(pos + 1) * K, m->e0m1 + (size_t)(pos + 1) * K, m->e2m0 + (size_t)(pos + 1) * K);
+    }
     fo_calculate_scaling_batch(cur, scal, sums, B, K);
     fo_apply_scaling_batch(cur, scal, B, K);
   }
+  free(zeros);
 
   /* ---- combine and normalise (HMM.cpp:669-692, NO_SSE) ---- */
   for (unsigned pos = from; pos < to; ++pos) {

@@ -43,6 +43,18 @@ typedef struct {
   const float* e1;       /* emission1AtSite      [S][K] */
   const float* e0m1;     /* emission0minus1AtSite[S][K] */
   const float* e2m0;     /* emission2minus0AtSite[S][K] */
+  /* sequence mode (decodingSequence, HMM.cpp:760-770, 915-925); all NULL / 0 in array mode.  Rows are indexed by
+   * the later site q of the gap (q-1, q):
+   *   gapRowF[q]  key roundMorgans(recDist_q - rate[q])   siteRowF[q] key rate[q]      (forward, into site q)
+   *   gapRowB[q]  key roundMorgans(recDist_q - rate[q-1]) siteRowB[q] key rate[q-1]    (backward, out of site q)
+   * with recDist_q = roundMorgans(gen[q]-gen[q-1]), rate[p] = roundMorgans(recRateAtMarker[p]);
+   *   hom[q] = homozygousEmissionMap[roundPhysical(phys[q]-phys[q-1]-1)]  [S][K] */
+  int32_t sequence;
+  const int32_t* gapRowF;
+  const int32_t* siteRowF;
+  const int32_t* gapRowB;
+  const int32_t* siteRowB;
+  const float* hom;
 } fo_model;
 
 /* One IBD record as handed to writePairIBD (HMM.cpp:1110-1177). */
@@ -74,8 +86,12 @@ unsigned long fo_subset_and(const uint8_t* v1, const uint8_t* v2, unsigned long 
                             unsigned long to, uint8_t* out);
 
 /*
- * HMM::decodeBatch (HMM.cpp:639-722) = forwardBatch (725-784, array mode) +
- * backwardBatch (882-940) + combine/normalise (669-692, NO_SSE branch).
+ * HMM::decodeBatch (HMM.cpp:639-722) = forwardBatch (725-784) + backwardBatch (882-940) +
+ * combine/normalise (669-692, NO_SSE branch); array mode, or sequence mode when m->sequence.
+ * Sequence mode keeps the reference's buffer semantics: `previousAlpha = nextAlpha` (HMM.cpp:767) and
+ * `lastComputedBeta = previousBeta` (922) are Eigen::Map assignments, i.e. they COPY the half-step result over
+ * the stored vector of the neighbouring site, so the posterior of site p is built from the un-scaled alpha after
+ * the homozygous half-step towards p+1 (p < to-1) and the beta after the half-step towards p-1 (p > from).
  * obsBits / homMinorBits: [B][to-from] bytes (what makeBits produced for the window).
  * alpha, beta: caller buffers of S*K*B floats, layout (pos*K + k)*B + v.
  * On return alpha holds the posterior for pos in [from,to); beta the scaled betas.

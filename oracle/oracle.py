@@ -34,6 +34,9 @@ class _FoModel(C.Structure):
         ("Dt", C.c_void_p), ("Bt", C.c_void_p), ("Ut", C.c_void_p), ("RRt", C.c_void_p),
         ("stepRow", C.c_void_p),
         ("e1", C.c_void_p), ("e0m1", C.c_void_p), ("e2m0", C.c_void_p),
+        ("sequence", C.c_int32),
+        ("gapRowF", C.c_void_p), ("siteRowF", C.c_void_p), ("gapRowB", C.c_void_p), ("siteRowB", C.c_void_p),
+        ("hom", C.c_void_p),
     ]
 
 
@@ -188,6 +191,13 @@ class PreparedModel:
     state_threshold: int
     age_threshold: int
     probability_threshold: np.float32
+    # sequence mode (decodingSequence): two steps per site, see hmm_oracle.h
+    sequence: bool = False
+    gap_row_f: np.ndarray | None = None  # [S] int32
+    site_row_f: np.ndarray | None = None
+    gap_row_b: np.ndarray | None = None
+    site_row_b: np.ndarray | None = None
+    hom: np.ndarray | None = None  # [S][K] f32
 
     def c_struct(self) -> _FoModel:
         m = _FoModel()
@@ -197,6 +207,11 @@ class PreparedModel:
         m.Dt, m.Bt, m.Ut, m.RRt = _p(self.D), _p(self.B), _p(self.U), _p(self.RR)
         m.stepRow = _p(self.step_row)
         m.e1, m.e0m1, m.e2m0 = _p(self.e1), _p(self.e0m1), _p(self.e2m0)
+        m.sequence = int(self.sequence)
+        if self.sequence:
+            m.gapRowF, m.siteRowF = _p(self.gap_row_f), _p(self.site_row_f)
+            m.gapRowB, m.siteRowB = _p(self.gap_row_b), _p(self.site_row_b)
+            m.hom = _p(self.hom)
         return m
 
 
@@ -221,14 +236,12 @@ def step_rows(tables_keys: np.ndarray, gen: np.ndarray) -> tuple[np.ndarray, np.
 
 def prepare_model(tables, gen, phys, derived_counts, total_samples: int, *, time: int = 50,
                   no_conditional_age_estimates: bool = True, fold: bool = True, decoding_sequence: bool = False,
-                  skip_csfs_distance: float = 0.0, known_seed: bool = True, compact_rows: bool = True
-                  ) -> PreparedModel:
-    """HMM::HMM + prepareEmissions for array data (folded or not), HMM.cpp:65-127, 159-256.
+                  skip_csfs_distance: float = 0.0, known_seed: bool = True, compact_rows: bool = True,
+                  rec_rate: np.ndarray | None = None) -> PreparedModel:
+    """HMM::HMM + prepareEmissions (folded or not, array or sequence mode), HMM.cpp:65-127, 159-256.
 
     ``tables`` is a fastsmc_amd.synth.ModelTables-like object (fields of DecodingQuantities).
-    Only decodingSequence == False (array mode) is restated; sequence mode is out of scope."""
-    if decoding_sequence:
-        raise NotImplementedError("sequence mode is outside the hot-path scope (SURVEY.md §8 f4)")
+    ``rec_rate``: Data::recRateAtMarker; default = the FastSMC-mode reader's values (rec_rate_at_marker)."""
     K = int(tables.K)
     gen = np.ascontiguousarray(gen, np.float32)
     S = gen.size
@@ -246,9 +259,10 @@ def prepare_model(tables, gen, phys, derived_counts, total_samples: int, *, time
     e1 = np.zeros((S, K), np.float32)
     e0m1 = np.zeros((S, K), np.float32)
     e2m0 = np.zeros((S, K), np.float32)
-    FAC = tables.folded_ascertained_csfs
-    ASC = tables.ascertained_csfs
-    comp = tables.compressed_emission
+    # sequence data: CSFS / folded CSFS / classic emission; array data: the ascertained ones (HMM.cpp:183-252)
+    FAC = tables.folded_csfs if decoding_sequence else tables.folded_ascertained_csfs
+    ASC = tables.csfs if decoding_sequence else tables.ascertained_csfs
+    comp = tables.classic_emission if decoding_sequence else tables.compressed_emission
     for pos in range(S):
         if use_csfs[pos]:
             u0, u1, u2 = (int(x) for x in und[pos])
@@ -269,10 +283,40 @@ def prepare_model(tables, gen, phys, derived_counts, total_samples: int, *, time
             e1[pos] = comp[1]
             e0m1[pos] = comp[0] - comp[1]
             e2m0[pos] = 0.0
-    full_rows, _ = step_rows(tables.keys, gen)
+    full_rows, step_keys = step_rows(tables.keys, gen)
+    seq_rows = []
+    hom = None
+    if decoding_sequence:
+        # HMM.cpp:752-770 (forward) and 905-925 (backward)
+        phys_i = np.ascontiguousarray(phys, np.int64)
+        rate = rec_rate_at_marker(gen, phys_i) if rec_rate is None else np.ascontiguousarray(rec_rate, np.float32)
+        key_to_row = {np.float32(k).tobytes(): i for i, k in enumerate(np.asarray(tables.keys, np.float32))}
+
+        def row_of(key, what, site):
+            r = key_to_row.get(np.float32(key).tobytes())
+            if r is None:
+                raise KeyError(f"no transition vectors for {what} key {key!r} (site {site})")
+            return r
+
+        gf, sf, gb, sb = (np.zeros(S, np.int32) for _ in range(4))
+        hom = np.zeros((S, K), np.float32)
+        hom_row = {int(k): i for i, k in enumerate(tables.homozygous_keys)}
+        for q in range(1, S):
+            rec_dist = step_keys[q]
+            rate_q, rate_p = round_morgans(rate[q]), round_morgans(rate[q - 1])
+            gf[q] = row_of(round_morgans(np.float32(rec_dist - rate_q)), "forward gap", q)
+            sf[q] = row_of(rate_q, "forward site", q)
+            gb[q] = row_of(round_morgans(np.float32(rec_dist - rate_p)), "backward gap", q)
+            sb[q] = row_of(rate_p, "backward site", q)
+            d = round_physical(int(phys_i[q] - phys_i[q - 1] - 1))
+            if d not in hom_row:  # unordered_map::at
+                raise KeyError(f"no homozygous emission for physical distance {d} (site {q})")
+            hom[q] = tables.homozygous[hom_row[d]]
+        seq_rows = [gf, sf, gb, sb]
     if compact_rows:
-        used, inv = np.unique(full_rows, return_inverse=True)
-        rows = inv.astype(np.int32)
+        used, inv = np.unique(np.concatenate([full_rows] + seq_rows), return_inverse=True)
+        inv = inv.astype(np.int32).reshape(1 + len(seq_rows), S)
+        rows, seq_rows = inv[0].copy(), [r.copy() for r in inv[1:]]
         D, B, U, RR = (np.ascontiguousarray(x[used]) for x in (tables.D, tables.B, tables.U, tables.RR))
     else:
         rows = full_rows
@@ -293,7 +337,24 @@ def prepare_model(tables, gen, phys, derived_counts, total_samples: int, *, time
         U=np.ascontiguousarray(U, np.float32), RR=np.ascontiguousarray(RR, np.float32),
         step_row=np.ascontiguousarray(rows, np.int32), e1=e1, e0m1=e0m1, e2m0=e2m0, gen=gen,
         phys=np.ascontiguousarray(phys, np.int32), state_threshold=st,
-        age_threshold=K if no_conditional_age_estimates else st, probability_threshold=pthr)
+        age_threshold=K if no_conditional_age_estimates else st, probability_threshold=pthr,
+        sequence=bool(decoding_sequence),
+        **(dict(gap_row_f=seq_rows[0], site_row_f=seq_rows[1], gap_row_b=seq_rows[2], site_row_b=seq_rows[3],
+                hom=hom) if decoding_sequence else {}))
+
+
+def rec_rate_at_marker(gen: np.ndarray, phys: np.ndarray) -> np.ndarray:
+    """Data::recRateAtMarker as the FastSMC-mode reader fills it (Data::addMarker, Data.cpp:549-565): the fp32
+    difference of genetic positions, promoted to double, divided by the integer distance, rounded to fp32; marker 0
+    takes the rate of marker 1."""
+    gen = np.ascontiguousarray(gen, np.float32)
+    phys = np.ascontiguousarray(phys, np.int64)
+    out = np.zeros(gen.size, np.float32)
+    for p in range(1, gen.size):
+        out[p] = np.float32(float(np.float32(gen[p] - gen[p - 1])) / float(int(phys[p] - phys[p - 1])))
+    if gen.size > 1:
+        out[0] = out[1]
+    return out
 
 
 # ------------------------------------------------------------ the hot path

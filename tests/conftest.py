@@ -26,3 +26,20 @@ def small_problem():
     gen = (haps.cm / 100.0).astype(np.float32)
     model = O.prepare_model(tables, gen, haps.bp, derived, 64, time=50)
     return dict(tables=tables, haps=haps, bits=bits, folded=folded, gen=gen, model=model)
+
+
+@pytest.fixture(scope="session")
+def seq_problem():
+    """Sequence-mode (decodingSequence) variant: denser sites with varying spacing, 64 haplotypes x 400 sites,
+    folded CSFS / classic emissions, two transition steps per site with a homozygous stretch in between."""
+    import numpy as np
+    from fastsmc_amd import synth
+    from oracle import oracle as O
+
+    tables = synth.make_model_tables(69)
+    haps = synth.make_haps(64, 400, seed=21, cm_per_mb=1.2, bp_per_site=2500, switch_per_cm=2.0)
+    bits, derived, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    gen = (haps.cm / 100.0).astype(np.float32)
+    model = O.prepare_model(tables, gen, haps.bp, derived, 64, time=50, decoding_sequence=True)
+    return dict(tables=tables, haps=haps, bits=bits, folded=folded, gen=gen, model=model)

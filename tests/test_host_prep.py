@@ -122,3 +122,66 @@ def test_params_defaults_match_reference():
     assert q.decodingMode == api.DecodingMode.array and not q.foldData
     with pytest.raises(RuntimeError):
         api.DecodingParams("in", "dq", decodingModeString="banana")
+
+
+def _assert_same_sequence_rows(pm_host: dict, pm_oracle):
+    assert pm_host["sequence"] and pm_oracle.sequence
+    for rows in ("gap_row_f", "site_row_f", "gap_row_b", "site_row_b"):
+        for name in ("D", "B", "U", "RR"):
+            got = pm_host[name][pm_host[rows][1:]]
+            want = getattr(pm_oracle, name)[getattr(pm_oracle, rows)[1:]]
+            np.testing.assert_array_equal(got, want, err_msg=f"{name}[{rows}]")
+    np.testing.assert_array_equal(pm_host["hom"][1:], pm_oracle.hom[1:])
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_prepared_model_sequence_mode(seq_problem, fold):
+    """decodingSequence: CSFS / folded CSFS / classic emissions (HMM.cpp:183-252), per-site rows of the two
+    transition steps and the homozygous emission between sites (HMM.cpp:752-770, 905-925)."""
+    sp = seq_problem
+    data = api.Data.from_arrays(sp["haps"].alleles, sp["haps"].bp, sp["haps"].cm, fold, True)
+    np.testing.assert_array_equal(np.array(data.recRateAtMarker, np.float32),
+                                  O.rec_rate_at_marker(sp["gen"], sp["haps"].bp))
+    dq = api.decoding_quantities_from_tables(sp["tables"])
+    p = _params(decodingSequence=True, decodingModeString="sequence", foldData=fold)
+    hmm = api.HMM(data, dq, p)
+    if fold:
+        want = sp["model"]
+    else:
+        derived = sp["haps"].alleles.sum(axis=0).astype(np.int32)
+        want = O.prepare_model(sp["tables"], sp["gen"], sp["haps"].bp, derived, 64, time=50, fold=False,
+                               decoding_sequence=True)
+    got = hmm.preparedModel()
+    _assert_same_model(got, want)
+    _assert_same_sequence_rows(got, want)
+
+
+def test_sequence_mode_files_round_trip(seq_problem, tmp_path):
+    """HomozygousEmissions / CSFS / FoldedCSFS / ClassicEmission sections through the file parser
+    (DecodingQuantities.cpp:283-284, 337-343), ASMC-mode readers (plink map, Data.cpp:162-210)."""
+    sp = seq_problem
+    root = str(tmp_path / "seq")
+    synth.write_haps_files(root, sp["haps"], fastsmc_map=False)
+    synth.write_decoding_quantities(root + ".decodingQuantities.gz", sp["tables"])
+    p = api.DecodingParams(root, root + ".decodingQuantities.gz", decodingModeString="sequence")
+    p.useKnownSeed = True
+    assert p.decodingSequence and p.foldData
+    dq = api.DecodingQuantities(root + ".decodingQuantities.gz")
+    hom = dq.homozygousEmissionMap
+    assert len(hom) == sp["tables"].homozygous_keys.size
+    np.testing.assert_array_equal(np.array(hom[1000], np.float32),
+                                  sp["tables"].homozygous[list(sp["tables"].homozygous_keys).index(1000)])
+    data = api.Data(p)
+    hmm = api.HMM(data, p)
+    got = hmm.preparedModel()
+    # the ASMC-mode map reader computes positions and rates in fp32 (Data.cpp:186-195)
+    gen = np.array(data.geneticPositions, np.float32)
+    phys = np.array(data.physicalPositions, np.int64)
+    rate = np.zeros(gen.size, np.float32)
+    rate[1:] = (gen[1:] - gen[:-1]) / (phys[1:] - phys[:-1]).astype(np.float32)
+    np.testing.assert_array_equal(np.array(data.recRateAtMarker, np.float32), rate)
+    _, derived, _ = synth.fold_and_pack(sp["haps"].alleles)
+    want = O.prepare_model(sp["tables"], gen, phys, derived, 64, time=p.time, decoding_sequence=True, rec_rate=rate,
+                           no_conditional_age_estimates=p.noConditionalAgeEstimates)
+    _assert_same_model(got, want)
+    _assert_same_sequence_rows(got, want)

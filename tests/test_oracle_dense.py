@@ -76,3 +76,55 @@ def test_lanes_are_independent(small_problem):
     post8, _ = O.decode_batch(m, ob, hb, 0, m.S)
     post4, _ = O.decode_batch(m, ob[4:], hb[4:], 0, m.S)
     np.testing.assert_array_equal(post8[:, :, 4:], post4)
+
+
+def dense_posterior_sequence(m, xbits, abits, frm, to):
+    """Sequence mode as the reference's buffers end up (HMM.cpp:760-770, 915-925 and hmm_oracle.h): the stored
+    alpha of site p < to-1 is the un-scaled vector after the homozygous half-step towards p+1, the stored beta of
+    site p > from the one after the half-step towards p-1."""
+    K = m.K
+    n = to - frm
+    Ts = {}
+
+    def T(row):
+        return Ts.setdefault(int(row), dense_T(m, int(row)))
+
+    hom = m.hom.astype(np.float64)
+    al = np.zeros((n, K))
+    be = np.zeros((n, K))
+    a = m.pi.astype(np.float64) * emission(m, frm, xbits[0], abits[0])
+    a /= a.sum()
+    for p in range(frm + 1, to):
+        half = hom[p] * (a @ T(m.gap_row_f[p]))
+        al[p - 1 - frm] = half
+        a = emission(m, p, xbits[p - frm], abits[p - frm]) * (half @ T(m.site_row_f[p]))
+        a /= a.sum()
+    al[n - 1] = a
+    b = np.full(K, 1.0 / K)
+    for p in range(to - 2, frm - 1, -1):
+        q = p + 1
+        half = T(m.gap_row_b[q]) @ (hom[q] * b)
+        be[q - frm] = half
+        b = T(m.site_row_b[q]) @ (emission(m, q, xbits[q - frm], abits[q - frm]) * half)
+        b /= b.sum()
+    be[0] = b
+    post = al * be
+    return post / post.sum(axis=1, keepdims=True)
+
+
+def test_oracle_sequence_mode_matches_dense_float64(seq_problem):
+    m = seq_problem["model"]
+    assert m.sequence and len(np.unique(m.gap_row_f)) > 10
+    folded = seq_problem["folded"]
+    pairs = [(0, 1), (3, 10), (5, 30), (20, 21)]
+    for frm, to in ((0, m.S), (37, 211), (5, 6)):
+        ob = np.stack([(folded[a] ^ folded[b])[frm:to] for a, b in pairs])
+        hb = np.stack([(folded[a] & folded[b])[frm:to] for a, b in pairs])
+        post, _ = O.decode_batch(m, ob, hb, frm, to)
+        for v in range(len(pairs)):
+            ref = dense_posterior_sequence(m, ob[v], hb[v], frm, to)
+            got = post[frm:to, :, v].astype(np.float64)
+            np.testing.assert_allclose(got.sum(axis=1), 1.0, rtol=1e-5)
+            assert np.max(np.abs(got - ref)) < 2e-5
+            big = ref > 1e-3
+            assert np.max(np.abs(got[big] / ref[big] - 1.0)) < 1e-3
