@@ -72,7 +72,9 @@ struct fsmc_model {
   float *pi = nullptr, *cR = nullptr, *expT = nullptr;
   float *D = nullptr, *B = nullptr, *U = nullptr, *RR = nullptr;
   int* stepRow = nullptr;
-  float4* emis3 = nullptr;
+  bool sequence = false;
+  int *rowGapF = nullptr, *rowSiteB = nullptr, *rowGapB = nullptr; // sequence mode (stepRow = forward site step)
+  float4* emis3 = nullptr; // [S][3 or 4][KP]: emission per observation class (+ the gap row in sequence mode)
   unsigned stateThr = 0, ageThr = 0;
   float probThr = 0.f;
 };
@@ -150,30 +152,35 @@ std::vector<float> padRows(const float* src, size_t rows, int K, int KP)
 
 using KernelFn = void (*)(const KParams);
 
-template <int MODE, bool TRACK> KernelFn pickKernel(int K)
+template <int MODE, bool TRACK, bool SEQ> KernelFn pickKernel(int K)
 {
   switch (K) {
   case 69:
-    return decode_kernel<69, MODE, TRACK>;
+    return decode_kernel<69, MODE, TRACK, SEQ>;
   default:
-    return decode_kernel<0, MODE, TRACK>;
+    return decode_kernel<0, MODE, TRACK, SEQ>;
   }
 }
 
-KernelFn pickKernel(int mode, bool track, int K)
+template <bool SEQ> KernelFn pickKernel(int mode, bool track, int K)
 {
   switch (mode) {
   case kModeIbd:
-    return track ? pickKernel<kModeIbd, true>(K) : pickKernel<kModeIbd, false>(K);
+    return track ? pickKernel<kModeIbd, true, SEQ>(K) : pickKernel<kModeIbd, false, SEQ>(K);
   case kModeDump:
-    return pickKernel<kModeDump, false>(K);
+    return pickKernel<kModeDump, false, SEQ>(K);
   case kModePerPair:
-    return pickKernel<kModePerPair, false>(K);
+    return pickKernel<kModePerPair, false, SEQ>(K);
   case kModeSums:
-    return pickKernel<kModeSums, false>(K);
+    return pickKernel<kModeSums, false, SEQ>(K);
   default:
     return nullptr;
   }
+}
+
+KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
+{
+  return m->sequence ? pickKernel<true>(mode, track, m->K) : pickKernel<false>(mode, track, m->K);
 }
 
 struct LaunchPlan {
@@ -281,6 +288,9 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.U = m->U;
   p.RR = m->RR;
   p.stepRow = m->stepRow;
+  p.rowGapF = m->rowGapF;
+  p.rowSiteB = m->rowSiteB;
+  p.rowGapB = m->rowGapB;
   p.emis3 = m->emis3;
   p.haps = ctx->dHaps;
   p.pairs = ctx->dPairs;
@@ -461,9 +471,19 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   if (d->state_threshold > (uint32_t)d->K || d->age_threshold > (uint32_t)d->K) {
     return fail(ctx, FSMC_EINVAL, "state/age threshold larger than K");
   }
-  for (int32_t s = 1; s < d->S; ++s) {
-    if (d->step_row[s] < 0 || d->step_row[s] >= d->n_rows) {
-      return fail(ctx, FSMC_EINVAL, "step_row[" + std::to_string(s) + "] outside the transition tables");
+  const bool seq = d->sequence != 0;
+  if (seq && (!d->gap_row_f || !d->site_row_f || !d->gap_row_b || !d->site_row_b || !d->hom)) {
+    return fail(ctx, FSMC_EINVAL, "sequence mode needs gap_row_f, site_row_f, gap_row_b, site_row_b and hom");
+  }
+  const int32_t* rowArrays[5] = {d->step_row, seq ? d->gap_row_f : nullptr, seq ? d->site_row_f : nullptr,
+                                 seq ? d->gap_row_b : nullptr, seq ? d->site_row_b : nullptr};
+  static const char* const rowNames[5] = {"step_row", "gap_row_f", "site_row_f", "gap_row_b", "site_row_b"};
+  for (int a = 0; a < 5; ++a) {
+    for (int32_t s = 1; rowArrays[a] && s < d->S; ++s) {
+      if (rowArrays[a][s] < 0 || rowArrays[a][s] >= d->n_rows) {
+        return fail(ctx, FSMC_EINVAL,
+                    std::string(rowNames[a]) + "[" + std::to_string(s) + "] outside the transition tables");
+      }
     }
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
@@ -494,26 +514,47 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   up(&m->B, d->B, (size_t)d->n_rows);
   up(&m->U, d->U, (size_t)d->n_rows);
   up(&m->RR, d->RR, (size_t)d->n_rows);
-  if (rc == FSMC_OK) {
-    std::vector<int> rows(d->step_row, d->step_row + d->S);
-    rows[0] = 0;
-    rc = upload(ctx, &m->stepRow, rows.data(), rows.size());
+  m->sequence = seq;
+  auto upRows = [&](int** dst, const int32_t* src) {
+    if (rc == FSMC_OK) {
+      std::vector<int> rows(src, src + d->S);
+      rows[0] = 0;
+      rc = upload(ctx, dst, rows.data(), rows.size());
+    }
+  };
+  // the kernel's "stepRow" is the (forward) site step: step_row in array mode, site_row_f in sequence mode
+  upRows(&m->stepRow, seq ? d->site_row_f : d->step_row);
+  if (seq) {
+    upRows(&m->rowGapF, d->gap_row_f);
+    upRows(&m->rowSiteB, d->site_row_b);
+    upRows(&m->rowGapB, d->gap_row_b);
   }
   if (rc == FSMC_OK) {
     // The reference evaluates e = (e1 + e0m1*isZero) + e2m0*isTwo with isZero/isTwo in {0,1}
     // (HMM.cpp:827-828, 959-961).  The three reachable (isZero,isTwo) combinations are tabulated
     // here with the same fp32 expression, so the kernel's row select is bit-identical.
-    std::vector<float> emis((size_t)d->S * 3 * KP, 0.f);
+    // Sequence mode adds a fourth row per site: the homozygous emission of the gap before it, which the reference
+    // passes as all three emission vectors with all-zero observations (HMM.cpp:764-766): (h + h*0) + h*0.
+    const int NC = seq ? 4 : 3;
+    std::vector<float> emis((size_t)d->S * NC * KP, 0.f);
     static const float zs[3] = {0.f, 1.f, 1.f};
     static const float ts[3] = {0.f, 0.f, 1.f};
     for (int32_t s = 0; s < d->S; ++s) {
       for (int c = 0; c < 3; ++c) {
-        float* dst = &emis[((size_t)s * 3 + c) * KP];
+        float* dst = &emis[((size_t)s * NC + c) * KP];
         const volatile float z = zs[c];
         const volatile float t = ts[c];
         for (int k = 0; k < K; ++k) {
           const size_t i = (size_t)s * K + k;
           dst[k] = d->e1[i] + d->e0m1[i] * z + d->e2m0[i] * t;
+        }
+      }
+      if (seq) {
+        float* dst = &emis[((size_t)s * NC + 3) * KP];
+        const volatile float zero = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float h = d->hom[(size_t)s * K + k];
+          dst[k] = h + h * zero + h * zero;
         }
       }
     }
@@ -542,7 +583,10 @@ void fsmc_model_destroy(fsmc_model* m)
   for (float* q : ptrs) {
     if (q) (void)hipFree(q);
   }
-  if (m->stepRow) (void)hipFree(m->stepRow);
+  int* rowPtrs[] = {m->stepRow, m->rowGapF, m->rowSiteB, m->rowGapB};
+  for (int* q : rowPtrs) {
+    if (q) (void)hipFree(q);
+  }
   delete m;
 }
 
@@ -614,7 +658,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   const bool track = (flags & (FSMC_WANT_MEAN | FSMC_WANT_MAP)) != 0;
-  KernelFn fn = pickKernel(kModeIbd, track, m->K);
+  KernelFn fn = pickKernel(kModeIbd, track, m);
   LaunchPlan plan;
   rc = planLaunch(ctx, m, kModeIbd, fn, plan);
   if (rc != FSMC_OK) {
@@ -747,7 +791,7 @@ int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_
   if (total > out_floats) {
     return fail(ctx, FSMC_EOVERFLOW, "posterior dump needs " + std::to_string(total) + " floats");
   }
-  KernelFn fn = pickKernel(kModeDump, false, m->K);
+  KernelFn fn = pickKernel(kModeDump, false, m);
   LaunchPlan plan;
   rc = planLaunch(ctx, m, kModeDump, fn, plan);
   if (rc == FSMC_OK) rc = ensure(ctx, ctx->aux, offsets.size() * sizeof(size_t));
@@ -780,7 +824,7 @@ int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model* m, const float* exp_co
     return fail(ctx, FSMC_EINVAL, "need expected coalescence times and at least one output");
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
-  KernelFn fn = pickKernel(kModePerPair, false, m->K);
+  KernelFn fn = pickKernel(kModePerPair, false, m);
   LaunchPlan plan;
   rc = planLaunch(ctx, m, kModePerPair, fn, plan);
   if (rc != FSMC_OK) {
@@ -839,7 +883,7 @@ int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sum
     return fail(ctx, FSMC_EUNSUPPORTED, "too many states for the sums transposition tile");
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
-  KernelFn fn = pickKernel(kModeSums, false, m->K);
+  KernelFn fn = pickKernel(kModeSums, false, m);
   LaunchPlan plan;
   rc = planLaunch(ctx, m, kModeSums, fn, plan);
   if (rc != FSMC_OK) {

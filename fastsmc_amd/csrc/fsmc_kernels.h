@@ -56,7 +56,10 @@ struct KParams {
   const float* B;
   const float* U;
   const float* RR;
-  const int* stepRow; // [S]
+  const int* stepRow; // [S] row of the step into site q (array mode); sequence mode: the site step, forward
+  const int* rowGapF; // sequence mode only: rows of the half-step across the gap (q-1, q), forward
+  const int* rowSiteB; //                     site step, backward (out of site q)
+  const int* rowGapB;  //                     gap half-step, backward
   const float4* emis3; // [S][3][KP/4]: emission rows for obs class het / hom-major / hom-minor
   const unsigned long long* haps; // [nHaps][W]
   const fsmc_pair* pairs;
@@ -183,7 +186,8 @@ template <int N> __device__ __forceinline__ EmisBlk<N> readEmis(const float4* e,
 // One step of the backward recursion for one pair (HMM.cpp:957-1016, NO_SSE association).
 // b: beta of site pos+1 (scaled) on entry, beta of site pos (scaled) on exit.  w: scratch.
 // e: this lane's emission row for site pos+1 (LDS).  Dr/Br/Ur/RRr: wave-uniform table rows.
-template <int KT, int KA>
+// SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:915-922).
+template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
                                           cfloat_p Ur, cfloat_p RRr, const float4* e, long long& waitCycles)
 {
@@ -263,16 +267,24 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
     d = nd;
     bt = nbt;
   }
-  const float c = 1.0f / sum;
+  if constexpr (SCALE) {
+    const float c = 1.0f / sum;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    b[k] = w[k] * c;
+    for (int k = 0; k < K; ++k) {
+      b[k] = w[k] * c;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      b[k] = w[k];
+    }
   }
 }
 
 // One step of the forward recursion (HMM.cpp:799-830) followed by the per-site scaling
 // (HmmUtils.cpp:102-151).  a: alpha of site pos-1 on entry, of site pos on exit.
-template <int KT, int KA>
+// SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:760-767).
+template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
                                            cfloat_p Ur, cfloat_p cR, const float4* e, long long& waitCycles)
 {
@@ -331,10 +343,17 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
     c4 = nc;
     em = nem;
   }
-  const float c = 1.0f / sum;
+  if constexpr (SCALE) {
+    const float c = 1.0f / sum;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    a[k] = w[k] * c;
+    for (int k = 0; k < K; ++k) {
+      a[k] = w[k] * c;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      a[k] = w[k];
+    }
   }
 }
 
@@ -446,25 +465,34 @@ __device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, c
   }
 }
 
-template <int KT, int MODE, bool TRACK>
+// SEQ: sequence mode (DecodingParams::decodingSequence) -- every site step is preceded by an un-normalised
+// half-step across the homozygous stretch since the neighbouring site, and the vectors the posterior is built
+// from are the ones the reference's buffers end up holding (HMM.cpp:767, 922; oracle/hmm_oracle.h):
+//   stored beta of site p  = beta after the half-step towards p-1 (p > from),
+//   stored alpha of site p = alpha after the half-step towards p+1 (p < to-1).
+// The emission ring then carries a fourth row per site: the homozygous emission of the gap before it.
+template <int KT, int MODE, bool TRACK, bool SEQ>
 __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 {
   constexpr int KA = KT > 0 ? KT : kMaxGenericK;
   constexpr int K4A = (KA + 3) / 4;
   constexpr int E4A = ((KA + kKPad - 1) / kKPad) * (kKPad / 4); // float4 per emission row (rows padded to kKPad)
-  constexpr int NL = (3 * E4A + kWave - 1) / kWave;       // float4 per lane to stage one site's rows
+  constexpr int NC = SEQ ? 4 : 3;                         // emission rows per site: 3 observation classes (+ gap)
+  constexpr int NL = (NC * E4A + kWave - 1) / kWave;      // float4 per lane to stage one site's rows
   const int K = KT > 0 ? KT : p.K;
   const int K4 = (K + 3) >> 2;
   const int KP = p.KP;
   const int E4 = KP >> 2;
 
-  __shared__ float4 emisLds[2][3 * E4A];  // ring of two sites x three observation classes
+  __shared__ float4 emisLds[2][NC * E4A]; // ring of two sites x three observation classes (+ the gap row)
   __shared__ float4 betaLds[K4A * kWave]; // landing zone of the next site's beta row (LDS-DMA)
 
   const int lane = threadIdx.x;
   const cfloat_p tD = (cfloat_p)p.D, tB = (cfloat_p)p.B, tU = (cfloat_p)p.U, tRR = (cfloat_p)p.RR;
   const cfloat_p tPi = (cfloat_p)p.pi, tCR = (cfloat_p)p.cR, tExpT = (cfloat_p)p.expT;
   const cint_p tStepRow = (cint_p)p.stepRow;
+  const cint_p tRowGapF = (cint_p)p.rowGapF, tRowSiteB = (cint_p)(SEQ ? p.rowSiteB : p.stepRow),
+               tRowGapB = (cint_p)p.rowGapB;
   const size_t vecF4 = (size_t)K4 * kWave; // float4 per stored K-vector of a wave
   float4* const chunkbuf = p.ws + (size_t)blockIdx.x * p.wsSlot;
   float4* const ckpt = chunkbuf + (size_t)p.chunk * vecF4;
@@ -532,8 +560,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       for (int i = 0; i < NL; ++i) {
         const int idx = lane + i * kWave;
         r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < 3 * E4) {
-          r.v[i] = p.emis3[(size_t)q * (3 * E4) + idx];
+        if (idx < NC * E4) {
+          r.v[i] = p.emis3[(size_t)q * (NC * E4) + idx];
         }
       }
       return r;
@@ -542,7 +570,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int idx = lane + i * kWave;
-        if (idx < 3 * E4) {
+        if (idx < NC * E4) {
           emisLds[q & 1][idx] = r.v[i];
         }
       }
@@ -565,6 +593,30 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 #define FSMC_STAMP(acc) ((void)0)
 #endif
 
+    // Sequence mode, backward.  The vector carried from site to site is the STORED one (after the half-step).
+    // betaGapStep: stage site q's rows (its fourth row is the homozygous emission of the gap (q-1, q)) and take
+    // the un-normalised half-step across that gap.  betaSeqStep: the site step out of q = pos+1 (whose rows the
+    // previous half-step left in the ring), then the half-step towards pos-1 unless pos is the window start.
+    auto betaGapStep = [&](float (&b)[KA], const int q, const EmisRegs& rows) {
+      commitEmis(q, rows);
+      const size_t row = (size_t)tRowGapB[q] * KP;
+      beta_step<KT, KA, false>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][3 * E4], cycW);
+    };
+    auto betaSeqStep = [&](float (&b)[KA], const int pos) {
+      const int q = pos + 1;
+      const bool gap = pos > from;
+      EmisRegs ev;
+      if (gap) {
+        ev = prefetchEmis(pos);
+      }
+      const int c = obsClass(q);
+      const size_t row = (size_t)tRowSiteB[q] * KP;
+      beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
+      if (gap) {
+        betaGapStep(b, pos, ev);
+      }
+    };
+
     // ------------------------------------------------------------------ pass B
     {
       float b[KA];
@@ -582,21 +634,33 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           }
         }
       };
-      afterBeta(to - 1);
-      EmisRegs ev;
-      if (to - 2 >= from) {
-        ev = prefetchEmis(to - 1);
-      }
-      for (int pos = to - 2; pos >= from; --pos) {
-        const int q = pos + 1;
-        commitEmis(q, ev);
-        if (pos - 1 >= from) {
-          ev = prefetchEmis(q - 1);
+      if constexpr (SEQ) {
+        if (to - 1 > from) {
+          betaGapStep(b, to - 1, prefetchEmis(to - 1));
         }
-        const int c = obsClass(q);
-        const size_t row = (size_t)tStepRow[q] * KP;
-        beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
-        afterBeta(pos);
+      }
+      afterBeta(to - 1);
+      if constexpr (SEQ) {
+        for (int pos = to - 2; pos >= from; --pos) {
+          betaSeqStep(b, pos);
+          afterBeta(pos);
+        }
+      } else {
+        EmisRegs ev;
+        if (to - 2 >= from) {
+          ev = prefetchEmis(to - 1);
+        }
+        for (int pos = to - 2; pos >= from; --pos) {
+          const int q = pos + 1;
+          commitEmis(q, ev);
+          if (pos - 1 >= from) {
+            ev = prefetchEmis(q - 1);
+          }
+          const int c = obsClass(q);
+          const size_t row = (size_t)tStepRow[q] * KP;
+          beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
+          afterBeta(pos);
+        }
       }
     }
 
@@ -654,26 +718,41 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           int pos;
           if (hi == to) {
             beta_init<KT, KA>(K, b);
+            if constexpr (SEQ) {
+              if (to - 1 > from) {
+                betaGapStep(b, to - 1, prefetchEmis(to - 1));
+              }
+            }
             store_vec<KT, KA>(K, chunkbuf + (size_t)(to - 1 - lo) * vecF4 + lane, b);
             pos = to - 2;
           } else {
             load_vec<KT, KA>(K, ckpt + (size_t)(j + 1) * vecF4 + lane, b);
             pos = hi - 1;
-          }
-          EmisRegs ev;
-          if (pos >= lo) {
-            ev = prefetchEmis(pos + 1);
-          }
-          for (; pos >= lo; --pos) {
-            const int q = pos + 1;
-            commitEmis(q, ev);
-            if (pos - 1 >= lo) {
-              ev = prefetchEmis(q - 1);
+            if constexpr (SEQ) {
+              commitEmis(hi, prefetchEmis(hi)); // the checkpoint is the stored vector of site hi: its rows next
             }
-            const int c = obsClass(q);
-            const size_t row = (size_t)tStepRow[q] * KP;
-            beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
-            store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
+          }
+          if constexpr (SEQ) {
+            for (; pos >= lo; --pos) {
+              betaSeqStep(b, pos);
+              store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
+            }
+          } else {
+            EmisRegs ev;
+            if (pos >= lo) {
+              ev = prefetchEmis(pos + 1);
+            }
+            for (; pos >= lo; --pos) {
+              const int q = pos + 1;
+              commitEmis(q, ev);
+              if (pos - 1 >= lo) {
+                ev = prefetchEmis(q - 1);
+              }
+              const int c = obsClass(q);
+              const size_t row = (size_t)tStepRow[q] * KP;
+              beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
+              store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
+            }
           }
         }
         if (j > 0) {
@@ -688,10 +767,19 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
       fetchBeta(chunkbuf + lane);
       EmisRegs ev = prefetchEmis(lo);
+      if constexpr (SEQ) {
+        commitEmis(lo, ev); // later sites are staged by the half-step of the site before them
+      }
       for (int pos = lo; pos < hi; ++pos) {
-        commitEmis(pos, ev);
-        if (pos + 1 < hi) {
-          ev = prefetchEmis(pos + 1);
+        if constexpr (SEQ) {
+          if (pos < to - 1) {
+            ev = prefetchEmis(pos + 1);
+          }
+        } else {
+          commitEmis(pos, ev);
+          if (pos + 1 < hi) {
+            ev = prefetchEmis(pos + 1);
+          }
         }
         const int c = obsClass(pos);
         const float4* e = &emisLds[pos & 1][c * E4];
@@ -700,6 +788,16 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         } else {
           const size_t row = (size_t)tStepRow[pos] * KP;
           alpha_step<KT, KA>(K, a, w, tD + row, tB + row, tU + row, tCR, e, cycW);
+        }
+        if constexpr (SEQ) {
+          // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step
+          // across the gap to the next site (HMM.cpp:764-767); the last site of the window keeps its alpha
+          if (pos < to - 1) {
+            commitEmis(pos + 1, ev);
+            const size_t row = (size_t)tRowGapF[pos + 1] * KP;
+            alpha_step<KT, KA, false>(K, a, w, tD + row, tB + row, tU + row, tCR, &emisLds[(pos + 1) & 1][3 * E4],
+                                      cycW);
+          }
         }
 
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
@@ -771,7 +869,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           // over pairs in batch order (local fp32 sum from 0.f), then added to the accumulator.  The K x 64 tile
           // is transposed through LDS (row stride 65 floats: conflict-free both ways); lane j then owns state j.
           float* const tile = reinterpret_cast<float*>(betaLds);
-          unsigned char* const cls = reinterpret_cast<unsigned char*>(&emisLds[(pos + 1) & 1][0]); // idle ring slot
+          // a ring slot whose rows are no longer needed: this site's in sequence mode, the other one otherwise
+          unsigned char* const cls = reinterpret_cast<unsigned char*>(&emisLds[(SEQ ? pos : pos + 1) & 1][0]);
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             tile[k * 65 + lane] = w[k] * cq;
