@@ -113,6 +113,9 @@ def main() -> None:
     ap.add_argument("--sites", type=int, default=50000)
     ap.add_argument("--states", type=int, default=69)
     ap.add_argument("--chunk-sites", type=int, default=0, help="sites between beta checkpoints (0 = automatic)")
+    ap.add_argument("--beta-stride", type=int, default=0,
+                    help="1 = every beta row through HBM, 2 = every second row (others recomputed), 0 = automatic")
+    ap.add_argument("--flags", type=int, default=-1, help="FSMC_WANT_* bits (default: mean + MAP ages)")
     ap.add_argument("--ws-frac", type=float, default=0.0, help="workspace cap as a fraction of HBM (0 = default)")
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs in the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -146,7 +149,9 @@ def main() -> None:
         ctx.set_chunk_sites(args.chunk_sites)
     if args.ws_frac:
         ctx.set_workspace_limit(int(args.ws_frac * ctx.info()["hbm_bytes"]))
-    flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
+    if args.beta_stride:
+        ctx.set_beta_stride(args.beta_stride)
+    flags = (capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP) if args.flags < 0 else args.flags
 
     from fastsmc_amd.dist import gather_ibd_records
 
@@ -200,6 +205,7 @@ def main() -> None:
                        "pair_sites_per_s": value * pm.S, "ibd_records_per_step": n_rec,
                        "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
                        "chunk_sites": info["chunk_sites"], "chunks_per_window": info["max_chunks"],
+                       "beta_stride": ctx.last_beta_stride(),
                        **({"phase_cycles": [int(x) for x in phase]} if phase.any() else {})},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": measured_traffic(args.haps, args.sites, pm.K),

@@ -26,7 +26,7 @@ FSMC_EOVERFLOW = -6
 # every symbol include/fastsmc_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
-    "fsmc_ctx_set_chunk_sites", "fsmc_ctx_last_plan",
+    "fsmc_ctx_set_chunk_sites", "fsmc_ctx_set_beta_stride", "fsmc_ctx_last_beta_stride", "fsmc_ctx_last_plan",
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
     "fsmc_decode_ibd",
@@ -81,6 +81,8 @@ def load():
         L.fsmc_ctx_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]
         L.fsmc_ctx_set_workspace_limit.argtypes = [vp, u64]
         L.fsmc_ctx_set_chunk_sites.argtypes = [vp, u32]
+        L.fsmc_ctx_set_beta_stride.argtypes = [vp, u32]
+        L.fsmc_ctx_last_beta_stride.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_ctx_last_plan.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.fsmc_model_create.argtypes = [vp, C.POINTER(_ModelDesc), C.POINTER(vp)]
         L.fsmc_model_destroy.argtypes = [vp]
@@ -158,6 +160,15 @@ class Context:
 
     def set_chunk_sites(self, sites: int):
         self._check(self._L.fsmc_ctx_set_chunk_sites(self._h, sites))
+
+    def set_beta_stride(self, stride: int):
+        """0 = automatic, 1 = every beta row through HBM, 2 = every second row (the others recomputed)."""
+        self._check(self._L.fsmc_ctx_set_beta_stride(self._h, stride))
+
+    def last_beta_stride(self) -> int:
+        v = C.c_int32(0)
+        self._check(self._L.fsmc_ctx_last_beta_stride(self._h, C.byref(v)))
+        return v.value
 
     def set_workspace_limit(self, nbytes: int):
         self._check(self._L.fsmc_ctx_set_workspace_limit(self._h, nbytes))

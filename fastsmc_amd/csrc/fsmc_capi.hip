@@ -60,6 +60,8 @@ struct fsmc_ctx {
   int lastSlots = 0;
   int lastChunk = 0, lastMaxChunks = 0;
   uint32_t chunkSites = 0; // 0 = automatic
+  uint32_t betaStride = 0; // 0 = automatic (2 where the kernel exists), 1 = store every beta row
+  int lastStride = 1;
 
   const fsmc_model* ibdModel = nullptr;
   uint32_t ibdFlags = 0;
@@ -152,35 +154,53 @@ std::vector<float> padRows(const float* src, size_t rows, int K, int KP)
 
 using KernelFn = void (*)(const KParams);
 
-template <int MODE, bool TRACK, bool SEQ> KernelFn pickKernel(int K)
+template <int MODE, bool TRACK, bool SEQ> KernelFn pickKernel(int K, bool half)
 {
   switch (K) {
   case 69:
-    return decode_kernel<69, MODE, TRACK, SEQ>;
+    if constexpr (MODE == kModeIbd && !SEQ) {
+      if (half) {
+        return decode_kernel<69, MODE, TRACK, SEQ, true>;
+      }
+    }
+    return decode_kernel<69, MODE, TRACK, SEQ, false>;
   default:
-    return decode_kernel<0, MODE, TRACK, SEQ>;
+    return decode_kernel<0, MODE, TRACK, SEQ, false>;
   }
 }
 
-template <bool SEQ> KernelFn pickKernel(int mode, bool track, int K)
+// Beta stride 2 (every second beta row stored, the others recomputed in the alpha sweep) exists for the
+// compile-time-K array-mode IBD decode -- the path BASELINE.json's metric is quoted on.
+bool halfAvailable(int mode, const fsmc_model* m);
+
+template <bool SEQ> KernelFn pickKernel(int mode, bool track, int K, bool half)
 {
   switch (mode) {
   case kModeIbd:
-    return track ? pickKernel<kModeIbd, true, SEQ>(K) : pickKernel<kModeIbd, false, SEQ>(K);
+    return track ? pickKernel<kModeIbd, true, SEQ>(K, half) : pickKernel<kModeIbd, false, SEQ>(K, half);
   case kModeDump:
-    return pickKernel<kModeDump, false, SEQ>(K);
+    return pickKernel<kModeDump, false, SEQ>(K, false);
   case kModePerPair:
-    return pickKernel<kModePerPair, false, SEQ>(K);
+    return pickKernel<kModePerPair, false, SEQ>(K, false);
   case kModeSums:
-    return pickKernel<kModeSums, false, SEQ>(K);
+    return pickKernel<kModeSums, false, SEQ>(K, false);
   default:
     return nullptr;
   }
 }
 
+bool halfAvailable(int mode, const fsmc_model* m)
+{
+  return mode == kModeIbd && !m->sequence && m->K == 69;
+}
+
 KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
 {
-  return m->sequence ? pickKernel<true>(mode, track, m->K) : pickKernel<false>(mode, track, m->K);
+  const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1;
+  if (mode == kModeIbd) {
+    m->ctx->lastStride = half ? 2 : 1;
+  }
+  return m->sequence ? pickKernel<true>(mode, track, m->K, false) : pickKernel<false>(mode, track, m->K, half);
 }
 
 struct LaunchPlan {
@@ -438,6 +458,24 @@ int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites)
     return FSMC_EINVAL;
   }
   ctx->chunkSites = sites;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_set_beta_stride(fsmc_ctx* ctx, uint32_t stride)
+{
+  if (!ctx || stride > 2) {
+    return fail(ctx, FSMC_EINVAL, "beta stride must be 0 (automatic), 1 or 2");
+  }
+  ctx->betaStride = stride;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride)
+{
+  if (!ctx || !stride) {
+    return FSMC_EINVAL;
+  }
+  *stride = ctx->lastStride;
   return FSMC_OK;
 }
 

@@ -428,37 +428,41 @@ template <int KT, int KA> __device__ __forceinline__ void load_vec(const int K, 
 }
 
 // Segment age estimates from the per-state posterior sums of a segment
-// (HMM::getPosteriorMean, HMM.cpp:1087-1097; HMM::getMAP, 1099-1107).
-template <int KT, int KA>
-__device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, const float (&sps)[KA], cfloat_p pi,
+// (HMM::getPosteriorMean, HMM.cpp:1087-1097; HMM::getMAP, 1099-1107).  The sums live in the wave's workspace
+// as [K/4][64 lanes] float4 (sps points at this lane's column); this runs once per IBD record, so it walks
+// memory with real loops instead of holding a K-vector in registers.
+__device__ __forceinline__ float spsAt(const float4* sps, const int k)
+{
+  return reinterpret_cast<const float*>(sps + (size_t)(k >> 2) * kWave)[k & 3];
+}
+__device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, const float4* sps, cfloat_p pi,
                                              cfloat_p expT, const bool wantMean, const bool wantMap, float& mean,
                                              float& mapv)
 {
   mean = 0.f;
   mapv = 0.f;
+  const int n = (unsigned)K < nAge ? K : (int)nAge;
   if (wantMean) {
     float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if ((unsigned)k < nAge) acc = acc + sps[k];
+#pragma nounroll
+    for (int k = 0; k < n; ++k) {
+      acc = acc + spsAt(sps, k);
     }
     const float norm = 1.f / acc;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if ((unsigned)k < nAge) mean = mean + (norm * sps[k]) * expT[k];
+#pragma nounroll
+    for (int k = 0; k < n; ++k) {
+      mean = mean + (norm * spsAt(sps, k)) * expT[k];
     }
   }
   if (wantMap) {
     float best = 0.f;
     float bestT = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if ((unsigned)k < nAge) {
-        const float r = sps[k] / pi[k];
-        if (k == 0 || best < r) {
-          best = r;
-          bestT = expT[k];
-        }
+#pragma nounroll
+    for (int k = 0; k < n; ++k) {
+      const float r = spsAt(sps, k) / pi[k];
+      if (k == 0 || best < r) {
+        best = r;
+        bestT = expT[k];
       }
     }
     mapv = bestT;
@@ -471,9 +475,15 @@ __device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, c
 //   stored beta of site p  = beta after the half-step towards p-1 (p > from),
 //   stored alpha of site p = alpha after the half-step towards p+1 (p < to-1).
 // The emission ring then carries a fourth row per site: the homozygous emission of the gap before it.
-template <int KT, int MODE, bool TRACK, bool SEQ>
+//
+// HALF: beta stride 2.  Within a chunk [lo, hi) only the beta rows of the sites at odd offsets
+// (and of the chunk's last site) are written to HBM; the alpha sweep recomputes the row of an even-offset site
+// from its successor's row (already landed in LDS) with one more beta step.  Half the HBM traffic of the beta
+// stream for half a sweep of extra arithmetic; the floating-point operations of every row are unchanged.
+template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF>
 __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 {
+  static_assert(!HALF || (!SEQ && MODE == kModeIbd), "beta stride 2 is built for the array-mode IBD decode");
   constexpr int KA = KT > 0 ? KT : kMaxGenericK;
   constexpr int K4A = (KA + 3) / 4;
   constexpr int E4A = ((KA + kKPad - 1) / kKPad) * (kKPad / 4); // float4 per emission row (rows padded to kKPad)
@@ -499,6 +509,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   float4* const saveA = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
   float4* const saveS = saveA + vecF4;
   const int C = p.chunk;
+  // per-state posterior sums of the open segments (TRACK), one column per lane
+  float4* const spsMem = saveS + threadIdx.x;
+  // chunk-buffer slot of the row stored for the site at offset rel of its chunk
+  auto slotOf = [](const int rel) -> size_t { return (size_t)(HALF ? (rel >> 1) : rel); };
 
   struct EmisRegs {
     float4 v[NL];
@@ -623,8 +637,9 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       beta_init<KT, KA>(K, b);
       auto afterBeta = [&](const int pos) {
         if (single) {
-          if (pos < aEnd) {
-            store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - from) * vecF4 + lane, b);
+          const int rel = pos - from;
+          if (pos < aEnd && (!HALF || (rel & 1) || pos == aEnd - 1)) {
+            store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4 + lane, b);
           }
         } else {
           const int rel = pos - from;
@@ -670,18 +685,13 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     int segStart = 0; // first site of the open segment
     float acc = 0.f;  // posteriorIBD
     float a[KA];
-    float sps[TRACK ? KA : 1];
-    if constexpr (TRACK) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) sps[k] = 0.f;
-    }
 
     auto emit = [&](const int s0, const int s1) {
       const unsigned idx = atomicAdd(&p.counters[1], 1u);
       float mean = 0.f, mapv = 0.f;
       if constexpr (TRACK) {
-        segment_ages<KT, KA>(K, p.ageThr, sps, tPi, tExpT, (p.flags & FSMC_WANT_MEAN) != 0,
-                             (p.flags & FSMC_WANT_MAP) != 0, mean, mapv);
+        segment_ages(K, p.ageThr, spsMem, tPi, tExpT, (p.flags & FSMC_WANT_MEAN) != 0,
+                     (p.flags & FSMC_WANT_MAP) != 0, mean, mapv);
       }
       if (idx < p.recCap) {
         fsmc_ibd_record r;
@@ -708,10 +718,9 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       const int lo = from + j * C;
       const int hi = (lo + C < aEnd) ? lo + C : aEnd;
       if (!single) {
-        // park the carried alpha (and per-state sums) while the chunk's betas are rebuilt
+        // park the carried alpha while the chunk's betas are rebuilt
         if (j > 0) {
           store_vec<KT, KA>(K, saveA + lane, a);
-          if constexpr (TRACK) store_vec<KT, KA>(K, saveS + lane, sps);
         }
         {
           float b[KA];
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
                 betaGapStep(b, to - 1, prefetchEmis(to - 1));
               }
             }
-            store_vec<KT, KA>(K, chunkbuf + (size_t)(to - 1 - lo) * vecF4 + lane, b);
+            store_vec<KT, KA>(K, chunkbuf + slotOf(to - 1 - lo) * vecF4 + lane, b);
             pos = to - 2;
           } else {
             load_vec<KT, KA>(K, ckpt + (size_t)(j + 1) * vecF4 + lane, b);
@@ -751,13 +760,15 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               const int c = obsClass(q);
               const size_t row = (size_t)tStepRow[q] * KP;
               beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
-              store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
+              const int rel = pos - lo;
+              if (!HALF || (rel & 1) || pos == hi - 1) {
+                store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4 + lane, b);
+              }
             }
           }
         }
         if (j > 0) {
           load_vec<KT, KA>(K, saveA + lane, a);
-          if constexpr (TRACK) load_vec<KT, KA>(K, saveS + lane, sps);
         }
       }
 
@@ -767,13 +778,36 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
       fetchBeta(chunkbuf + lane);
       EmisRegs ev = prefetchEmis(lo);
+      EmisRegs ev2 = ev; // HALF: the rows of the second site of a pair of sites
       if constexpr (SEQ) {
         commitEmis(lo, ev); // later sites are staged by the half-step of the site before them
       }
+      if constexpr (HALF) {
+        if (lo + 1 < hi) {
+          ev2 = prefetchEmis(lo + 1);
+        }
+      }
       for (int pos = lo; pos < hi; ++pos) {
+        // HALF: this site's beta row was not stored -- it is recomputed below from the row of site pos+1
+        const bool rec = HALF && ((pos - lo) & 1) == 0 && pos + 1 < hi;
         if constexpr (SEQ) {
           if (pos < to - 1) {
             ev = prefetchEmis(pos + 1);
+          }
+        } else if constexpr (HALF) {
+          // sites are taken two at a time: stage the rows of both (the beta step back from pos+1 needs them
+          // before the alpha step into pos+1 does), and request the next two
+          if (((pos - lo) & 1) == 0) {
+            commitEmis(pos, ev);
+            if (rec) {
+              commitEmis(pos + 1, ev2);
+            }
+            if (pos + 2 < hi) {
+              ev = prefetchEmis(pos + 2);
+            }
+            if (pos + 3 < hi) {
+              ev2 = prefetchEmis(pos + 3);
+            }
           }
         } else {
           commitEmis(pos, ev);
@@ -804,7 +838,28 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         float sumq = 0.f;
-        {
+        if (rec) {
+          // the landing zone holds beta of site pos+1: one beta step back gives this site's row (the same
+          // operations, on the same bits, as the pass that stored its neighbours), combined from registers
+          float b[KA];
+#pragma unroll
+          for (int k4 = 0; k4 < K4; ++k4) {
+            const float4 o = betaLds[k4 * kWave + lane];
+            b[4 * k4] = o.x;
+            if (4 * k4 + 1 < K) b[4 * k4 + 1] = o.y;
+            if (4 * k4 + 2 < K) b[4 * k4 + 2] = o.z;
+            if (4 * k4 + 3 < K) b[4 * k4 + 3] = o.w;
+          }
+          const int q = pos + 1;
+          const int cq1 = obsClass(q);
+          const size_t rowq = (size_t)tStepRow[q] * KP;
+          beta_step<KT, KA>(K, b, w, tD + rowq, tB + rowq, tU + rowq, tRR + rowq, &emisLds[q & 1][cq1 * E4], cycW);
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            w[k] = a[k] * b[k];
+            sumq = sumq + w[k];
+          }
+        } else {
           constexpr int kCB = 8; // states per block of the combine
           const int NB = (K + kCB - 1) / kCB;
           auto loadB = [&](const int blk, float4& b0, float4& b1) {
@@ -838,8 +893,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         const float cq = 1.0f / sumq;
         // every read of the landing zone has returned: request the next site's beta row
         FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (MODE != kModeSums && pos + 1 < hi) {
-          fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4 + lane);
+        if (MODE != kModeSums && !rec && pos + 1 < hi) {
+          fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4 + lane);
         }
 
         if (MODE == kModePerPair) {
@@ -908,7 +963,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_wave_barrier();
           if (pos + 1 < hi) {
-            fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4 + lane);
+            fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4 + lane);
           }
         }
 
@@ -952,15 +1007,21 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
             const bool opening = level != 4 && level != cur;
             if constexpr (TRACK) {
+              // per-state posterior sums of the open segment (sum_posterior_per_state, HMM.cpp:1212-1229): kept
+              // in the wave's workspace, touched only by the lanes that are inside a segment at this site
               if (level != 4) {
 #pragma unroll
                 for (int k4 = 0; k4 < K4; ++k4) {
                   if ((unsigned)(4 * k4) < p.ageThr) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                      const int k = 4 * k4 + i;
-                      if (k < K && (unsigned)k < p.ageThr) sps[k] = (opening ? 0.f : sps[k]) + w[k];
+                    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!opening) {
+                      sv = spsMem[(size_t)k4 * kWave];
                     }
+                    sv.x = sv.x + w[4 * k4];
+                    if (4 * k4 + 1 < K) sv.y = sv.y + w[4 * k4 + 1];
+                    if (4 * k4 + 2 < K) sv.z = sv.z + w[4 * k4 + 2];
+                    if (4 * k4 + 3 < K) sv.w = sv.w + w[4 * k4 + 3];
+                    spsMem[(size_t)k4 * kWave] = sv;
                   }
                 }
               }
