@@ -116,6 +116,8 @@ def main() -> None:
     ap.add_argument("--beta-stride", type=int, default=0,
                     help="1 = every beta row through HBM, 2 = every second row (others recomputed), 0 = automatic")
     ap.add_argument("--flags", type=int, default=-1, help="FSMC_WANT_* bits (default: mean + MAP ages)")
+    ap.add_argument("--diag-same-row", action="store_true",
+                    help="diagnostic, NOT a result: every site uses the same transition-table row (scalar-cache hits)")
     ap.add_argument("--ws-frac", type=float, default=0.0, help="workspace cap as a fraction of HBM (0 = default)")
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs in the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -141,6 +143,8 @@ def main() -> None:
     n_pairs = int(pairs.shape[0])
     groups = capi.whole_sequence_groups(n_pairs, pm.S, batch=64)
 
+    if args.diag_same_row:
+        pm.step_row = np.full_like(pm.step_row, pm.step_row[1])
     ctx = capi.Context(local_rank)
     model = ctx.create_model(pm)
     ctx.upload_haps(bits, pm.S)
@@ -206,6 +210,7 @@ def main() -> None:
                        "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
                        "chunk_sites": info["chunk_sites"], "chunks_per_window": info["max_chunks"],
                        "beta_stride": ctx.last_beta_stride(),
+                       **({"DIAGNOSTIC_same_row": True} if args.diag_same_row else {}),
                        **({"phase_cycles": [int(x) for x in phase]} if phase.any() else {})},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": measured_traffic(args.haps, args.sites, pm.K),

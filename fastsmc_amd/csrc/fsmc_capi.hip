@@ -73,6 +73,7 @@ struct fsmc_model {
   int K = 0, KP = 0, S = 0, nRows = 0;
   float *pi = nullptr, *cR = nullptr, *expT = nullptr;
   float *D = nullptr, *B = nullptr, *U = nullptr, *RR = nullptr;
+  float* rowSets = nullptr; // [rows][5][KP]: D | B | U | Ush | RR per key, Ush[k] = U[k-1] (kernels' RowSet)
   int* stepRow = nullptr;
   bool sequence = false;
   int *rowGapF = nullptr, *rowSiteB = nullptr, *rowGapB = nullptr; // sequence mode (stepRow = forward site step)
@@ -306,6 +307,7 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.D = m->D;
   p.B = m->B;
   p.U = m->U;
+  p.rowSets = m->rowSets;
   p.RR = m->RR;
   p.stepRow = m->stepRow;
   p.rowGapF = m->rowGapF;
@@ -552,6 +554,26 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   up(&m->B, d->B, (size_t)d->n_rows);
   up(&m->U, d->U, (size_t)d->n_rows);
   up(&m->RR, d->RR, (size_t)d->n_rows);
+  if (rc == FSMC_OK) {
+    // RowSet copy for the packed steps: the rows of one key side by side so that one base register and
+    // immediate offsets address all of them.  Ush is U moved up one state: the packed beta step multiplies
+    // vec[k] = beta[k]*e[k] by U[k-1] (the term U[k-1]*vec[k] of BU[k-1], HMM.cpp:986-1005).
+    const size_t n = (size_t)d->n_rows;
+    std::vector<float> rs(n * kRowSetParts * (size_t)KP, 0.f);
+    for (size_t r = 0; r < n; ++r) {
+      float* q = &rs[r * kRowSetParts * KP];
+      for (int k = 0; k < K; ++k) {
+        q[kRowD * KP + k] = d->D[r * K + k];
+        q[kRowB * KP + k] = d->B[r * K + k];
+        q[kRowU * KP + k] = d->U[r * K + k];
+        q[kRowRR * KP + k] = d->RR[r * K + k];
+        if (k >= 1) {
+          q[kRowUsh * KP + k] = d->U[r * K + (k - 1)];
+        }
+      }
+    }
+    rc = upload(ctx, &m->rowSets, rs.data(), rs.size());
+  }
   m->sequence = seq;
   auto upRows = [&](int** dst, const int32_t* src) {
     if (rc == FSMC_OK) {
@@ -617,7 +639,7 @@ void fsmc_model_destroy(fsmc_model* m)
       m->ctx->ibdModel = nullptr;
     }
   }
-  float* ptrs[] = {m->pi, m->cR, m->expT, m->D, m->B, m->U, m->RR, (float*)m->emis3};
+  float* ptrs[] = {m->pi, m->cR, m->expT, m->D, m->B, m->U, m->rowSets, m->RR, (float*)m->emis3};
   for (float* q : ptrs) {
     if (q) (void)hipFree(q);
   }

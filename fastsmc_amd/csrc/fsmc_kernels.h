@@ -33,6 +33,7 @@ constexpr int kWave = 64;
 typedef const float __attribute__((address_space(4))) * cfloat_p;
 typedef const int __attribute__((address_space(4))) * cint_p;
 typedef const unsigned __attribute__((address_space(4))) * cuint_p;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -55,6 +56,7 @@ struct KParams {
   const float* D;     // [rows][KP]
   const float* B;
   const float* U;
+  const float* rowSets; // [rows][5][KP]: D | B | U | Ush | RR of one key side by side, Ush[k] = U[k-1] (packed steps)
   const float* RR;
   const int* stepRow; // [S] row of the step into site q (array mode); sequence mode: the site step, forward
   const int* rowGapF; // sequence mode only: rows of the half-step across the gap (q-1, q), forward
@@ -110,6 +112,20 @@ __device__ __forceinline__ f32x8 sload8(cfloat_p p)
   FSMC_GCN_ASM("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p));
   return v;
 }
+// The same loads with the block's byte offset as an instruction immediate (compile-time K: the unrolled block
+// index is a constant by the time the instruction is selected) -- no scalar address arithmetic per load.
+__device__ __forceinline__ f32x4 sload4(cfloat_p p, const int byteOff)
+{
+  f32x4 v = {};
+  FSMC_GCN_ASM("s_load_dwordx4 %0, %1, %2" : "=s"(v) : "s"(p), "i"(byteOff));
+  return v;
+}
+__device__ __forceinline__ f32x8 sload8(cfloat_p p, const int byteOff)
+{
+  f32x8 v = {};
+  FSMC_GCN_ASM("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(p), "i"(byteOff));
+  return v;
+}
 #define FSMC_SWAIT_INSN "s_waitcnt lgkmcnt(0)"
 __device__ __forceinline__ f32x16 sload16(cfloat_p p)
 {
@@ -131,9 +147,26 @@ __device__ __forceinline__ void swait(f32x8& a, f32x8& b, f32x8& c, f32x8& d)
 }
 // block-width dispatch so the block sizes below are tunable
 template <int N> struct SV;
-template <> struct SV<4> { typedef f32x4 T; static __device__ __forceinline__ T load(cfloat_p p) { return sload4(p); } };
-template <> struct SV<8> { typedef f32x8 T; static __device__ __forceinline__ T load(cfloat_p p) { return sload8(p); } };
-template <> struct SV<16> { typedef f32x16 T; static __device__ __forceinline__ T load(cfloat_p p) { return sload16(p); } };
+template <> struct SV<4> {
+  typedef f32x4 T;
+  static __device__ __forceinline__ T load(cfloat_p p) { return sload4(p); }
+  static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState) { return sload4(p, firstState * 4); }
+};
+template <> struct SV<8> {
+  typedef f32x8 T;
+  static __device__ __forceinline__ T load(cfloat_p p) { return sload8(p); }
+  static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState) { return sload8(p, firstState * 4); }
+};
+template <> struct SV<16> {
+  typedef f32x16 T;
+  static __device__ __forceinline__ T load(cfloat_p p) { return sload16(p); }
+  static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState)
+  {
+    f32x16 v = {};
+    FSMC_GCN_ASM("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "i"(firstState * 4));
+    return v;
+  }
+};
 __device__ __forceinline__ void swait(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
 {
   FSMC_GCN_ASM(FSMC_SWAIT_INSN : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
@@ -159,6 +192,8 @@ __device__ __forceinline__ void swait(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
 constexpr int kKB = FSMC_KB;   // states per operand block of the beta passes (two tables at a time)
 constexpr int kKBF = FSMC_KBF; // states per operand block of the alpha pass (four tables at a time)
 constexpr int kKPad = 16;      // table / emission rows are zero padded to a multiple of this many floats
+// RowSet: the transition-table rows of one key side by side, [key][5][KP] floats (packed steps)
+enum RowSetPart : int { kRowD = 0, kRowB = 1, kRowU = 2, kRowUsh = 3, kRowRR = 4, kRowSetParts = 5 };
 
 __device__ __forceinline__ float pick(const float4& e0, const float4& e1, const int i)
 {
@@ -172,7 +207,19 @@ template <int N> struct EmisBlk { // this lane's emission values of one operand 
     const float4& q = v[i >> 2];
     return (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
   }
+  __device__ __forceinline__ f32x2 pair(const int i) const // values i, i+1 (i even): one 64-bit register pair
+  {
+    const float4& q = v[i >> 2];
+    const f32x2 lo = {q.x, q.y}, hi = {q.z, q.w};
+    return (i & 2) == 0 ? lo : hi;
+  }
 };
+// values i, i+1 (i even) of a scalar operand block: an aligned SGPR pair
+template <typename V> __device__ __forceinline__ f32x2 pairOf(const V& v, const int i)
+{
+  const f32x2 r = {v[i], v[i + 1]};
+  return r;
+}
 template <int N> __device__ __forceinline__ EmisBlk<N> readEmis(const float4* e, const int blk)
 {
   EmisBlk<N> r;
@@ -188,8 +235,8 @@ template <int N> __device__ __forceinline__ EmisBlk<N> readEmis(const float4* e,
 // e: this lane's emission row for site pos+1 (LDS).  Dr/Br/Ur/RRr: wave-uniform table rows.
 // SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:915-922).
 template <int KT, int KA, bool SCALE = true>
-__device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                          cfloat_p Ur, cfloat_p RRr, const float4* e, long long& waitCycles)
+__device__ __forceinline__ void beta_step_1(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
+                                            cfloat_p Ur, cfloat_p RRr, const float4* e, long long& waitCycles)
 {
   typedef typename SV<kKB>::T SVec;
   const int NB = (K + kKB - 1) / kKB;
@@ -285,8 +332,8 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
 // (HmmUtils.cpp:102-151).  a: alpha of site pos-1 on entry, of site pos on exit.
 // SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:760-767).
 template <int KT, int KA, bool SCALE = true>
-__device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                           cfloat_p Ur, cfloat_p cR, const float4* e, long long& waitCycles)
+__device__ __forceinline__ void alpha_step_1(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
+                                             cfloat_p Ur, cfloat_p cR, const float4* e, long long& waitCycles)
 {
   typedef typename SV<kKBF>::T SVec;
   const int NB = (K + kKBF - 1) / kKBF;
@@ -354,6 +401,283 @@ __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&
     for (int k = 0; k < K; ++k) {
       a[k] = w[k];
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Packed variants of the two steps for a compile-time K.  gfx950 multiplies / adds two fp32 values per lane in one
+// VALU instruction (v_pk_mul_f32, v_pk_add_f32) when both sit in an aligned register pair.  Every operation of a
+// step that is not part of a first-order recurrence is done for states (k, k+1) at once; the recurrences (BU, BL,
+// AU, the suffix sum, the scaling sum) stay scalar and sequential.  Each value is produced by the same IEEE
+// operation on the same operands as in the scalar step (no FMA, no re-association), so the results are
+// bit-identical; only ~7.5 instead of 11 VALU instructions are issued per state.
+//
+// Backward: the term U[k]*vec[k+1] of BU[k] is taken from T[m] = Ush[m]*vec[m] with Ush[m] = U[m-1]
+// (a second copy of the U table shifted by one state), so that both factors share a state index.
+template <int KT, int KA, bool SCALE = true>
+__device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfloat_p rowSet, const float4* e,
+                                             long long& waitCycles)
+{
+  constexpr int K = KT;
+  // the five table rows of one key sit side by side (RowSet): one base register, block offsets as immediates
+  constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
+  typedef typename SV<kKB>::T SVec;
+  constexpr int NB = (K + kKB - 1) / kKB;
+  SVec u = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (NB - 1) * kKB);
+  SVec rr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (NB - 1) * kKB);
+  EmisBlk<kKB> em = readEmis<kKB>(e, NB - 1);
+  SVec d, bt;
+  float tcarry = 0.f; // T of the first state of the block above
+#pragma unroll
+  for (int blk = NB - 1; blk >= 0; --blk) {
+    FSMC_SWAIT(waitCycles, u, rr);
+    SVec nu = u, nrr = rr;
+    EmisBlk<kKB> nem = em;
+    if (blk > 0) {
+      nu = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (blk - 1) * kKB);
+      nrr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (blk - 1) * kKB);
+      nem = readEmis<kKB>(e, blk - 1);
+    } else {
+      d = SV<kKB>::loadAt(rowSet, kRowD * KPc + 0);
+      bt = SV<kKB>::loadAt(rowSet, kRowB * KPc + 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float T[kKB + 1];
+    T[kKB] = tcarry;
+    // vec[k] = beta[k]*e[k] (kept in b), T[k] = U[k-1]*vec[k]
+#pragma unroll
+    for (int i = 0; i < kKB; i += 2) {
+      const int k = blk * kKB + i;
+      if (k + 1 < K) {
+        f32x2 v = {b[k], b[k + 1]};
+        v = v * em.pair(i);
+        const f32x2 t = pairOf(u, i) * v;
+        b[k] = v.x;
+        b[k + 1] = v.y;
+        T[i] = t.x;
+        T[i + 1] = t.y;
+      } else if (k < K) {
+        b[k] = b[k] * em.at(i);
+        T[i] = u[i] * b[k];
+      }
+    }
+    // BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1], BU[K-1] = 0 (HMM.cpp:986-1005)
+#pragma unroll
+    for (int i = kKB - 1; i >= 0; --i) {
+      const int k = blk * kKB + i;
+      if (k < K) {
+        if (k == K - 1) {
+          w[k] = 0.f;
+        } else {
+          w[k] = T[i + 1] + rr[i] * w[k + 1];
+        }
+      }
+    }
+    tcarry = T[0];
+    u = nu;
+    rr = nrr;
+    em = nem;
+  }
+  // ascending: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k]
+  float BL = 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    FSMC_SWAIT(waitCycles, d, bt);
+    SVec nd = d, nbt = bt;
+    if (blk + 1 < NB) {
+      nd = SV<kKB>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKB);
+      nbt = SV<kKB>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKB);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < kKB; i += 2) {
+      const int k = blk * kKB + i;
+      if (k + 1 < K) {
+        const f32x2 v = {b[k], b[k + 1]};
+        const f32x2 dv = pairOf(d, i) * v;
+        const f32x2 bv = pairOf(bt, i) * v;
+        f32x2 bl;
+        bl.x = BL;
+        bl.y = BL + bv.x;
+        f32x2 x = bl + dv;
+        const f32x2 bu = {w[k], w[k + 1]};
+        x = x + bu;
+        w[k] = x.x;
+        w[k + 1] = x.y;
+        sum = sum + x.x;
+        sum = sum + x.y;
+        BL = (k + 1 < K - 1) ? bl.y + bv.y : bl.y;
+      } else if (k < K) {
+        w[k] = (BL + d[i] * b[k]) + w[k];
+        sum = sum + w[k];
+        if (k < K - 1) {
+          BL = BL + bt[i] * b[k];
+        }
+      }
+    }
+    d = nd;
+    bt = nbt;
+  }
+  if constexpr (SCALE) {
+    const float c = 1.0f / sum;
+    const f32x2 cc = {c, c};
+#pragma unroll
+    for (int k = 0; k < K; k += 2) {
+      if (k + 1 < K) {
+        const f32x2 x = {w[k], w[k + 1]};
+        const f32x2 y = x * cc;
+        b[k] = y.x;
+        b[k + 1] = y.y;
+      } else {
+        b[k] = w[k] * c;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      b[k] = w[k];
+    }
+  }
+}
+
+// Forward.  The suffix sums are kept one slot down (w[k] = alphaC[k+1]) so that B[k]*alphaC[k+1] pairs up with the
+// other products of state k; alphaC[0] is never used (HMM.cpp:799-830).
+template <int KT, int KA, bool SCALE = true>
+__device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cfloat_p rowSet, cfloat_p cR,
+                                              const float4* e, long long& waitCycles)
+{
+  constexpr int K = KT;
+  constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
+  static_assert(K >= 2, "packed step needs at least two states");
+  typedef typename SV<kKBF>::T SVec;
+  constexpr int NB = (K + kKBF - 1) / kKBF;
+  SVec d = SV<kKBF>::loadAt(rowSet, kRowD * KPc + 0), bt = SV<kKBF>::loadAt(rowSet, kRowB * KPc + 0), u = SV<kKBF>::loadAt(rowSet, kRowU * KPc + 0), c4 = SV<kKBF>::loadAt(cR, 0);
+  EmisBlk<kKBF> em = readEmis<kKBF>(e, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  w[K - 2] = a[K - 1];
+#pragma unroll
+  for (int k = K - 2; k >= 1; --k) {
+    w[k - 1] = w[k] + a[k];
+  }
+  float AU = 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    FSMC_SWAIT(waitCycles, d, bt, u, c4);
+    SVec nd = d, nbt = bt, nu = u, nc = c4;
+    EmisBlk<kKBF> nem = em;
+    if (blk + 1 < NB) {
+      nd = SV<kKBF>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKBF);
+      nbt = SV<kKBF>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKBF);
+      nu = SV<kKBF>::loadAt(rowSet, kRowU * KPc + (blk + 1) * kKBF);
+      nc = SV<kKBF>::loadAt(cR, (blk + 1) * kKBF);
+      nem = readEmis<kKBF>(e, blk + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < kKBF; i += 2) {
+      const int k = blk * kKBF + i;
+      if (k + 1 < K - 1) {
+        const f32x2 av = {a[k], a[k + 1]};
+        const f32x2 da = pairOf(d, i) * av;
+        const f32x2 ua = pairOf(u, i) * av;
+        const f32x2 ac = {w[k], w[k + 1]};
+        const f32x2 bw = pairOf(bt, i) * ac;
+        f32x2 au;
+        au.x = AU;
+        au.y = ua.x + c4[i] * AU; // AU of state k+1
+        f32x2 term = au + da;
+        term = term + bw;
+        const f32x2 o = em.pair(i) * term;
+        w[k] = o.x;
+        w[k + 1] = o.y;
+        sum = sum + o.x;
+        sum = sum + o.y;
+        AU = ua.y + c4[i + 1] * au.y; // AU of state k+2
+      } else {
+#pragma unroll
+        for (int ii = i; ii < i + 2; ++ii) {
+          const int kk = blk * kKBF + ii;
+          if (kk < K) {
+            float term = AU + d[ii] * a[kk];
+            if (kk < K - 1) {
+              term = term + bt[ii] * w[kk];
+            }
+            w[kk] = em.at(ii) * term;
+            sum = sum + w[kk];
+            if (kk < K - 1) {
+              AU = u[ii] * a[kk] + c4[ii] * AU;
+            }
+          }
+        }
+      }
+    }
+    d = nd;
+    bt = nbt;
+    u = nu;
+    c4 = nc;
+    em = nem;
+  }
+  if constexpr (SCALE) {
+    const float c = 1.0f / sum;
+    const f32x2 cc = {c, c};
+#pragma unroll
+    for (int k = 0; k < K; k += 2) {
+      if (k + 1 < K) {
+        const f32x2 x = {w[k], w[k + 1]};
+        const f32x2 y = x * cc;
+        a[k] = y.x;
+        a[k + 1] = y.y;
+      } else {
+        a[k] = w[k] * c;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      a[k] = w[k];
+    }
+  }
+}
+
+#if defined(FSMC_NO_PK)
+constexpr bool kPacked = false;
+#else
+constexpr bool kPacked = true;
+#endif
+
+// The tables as the kernel addresses them: `row` selects the key.  Packed steps read the RowSet copy, the generic
+// (runtime-K) steps the four separate tables.
+struct Tables {
+  cfloat_p D, B, U, RR, rowSets, cR;
+  int KP;
+};
+
+template <int KT, int KA, bool SCALE = true>
+__device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], const Tables& t, const int row,
+                                          const float4* e, long long& waitCycles)
+{
+  if constexpr (KT > 0 && kPacked) {
+    constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
+    beta_step_pk<KT, KA, SCALE>(b, w, t.rowSets + (size_t)row * (kRowSetParts * KPc), e, waitCycles);
+  } else {
+    const size_t o = (size_t)row * t.KP;
+    beta_step_1<KT, KA, SCALE>(K, b, w, t.D + o, t.B + o, t.U + o, t.RR + o, e, waitCycles);
+  }
+}
+
+template <int KT, int KA, bool SCALE = true>
+__device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], const Tables& t, const int row,
+                                           const float4* e, long long& waitCycles)
+{
+  if constexpr (KT > 0 && kPacked) {
+    constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
+    alpha_step_pk<KT, KA, SCALE>(a, w, t.rowSets + (size_t)row * (kRowSetParts * KPc), t.cR, e, waitCycles);
+  } else {
+    const size_t o = (size_t)row * t.KP;
+    alpha_step_1<KT, KA, SCALE>(K, a, w, t.D + o, t.B + o, t.U + o, t.cR, e, waitCycles);
   }
 }
 
@@ -500,6 +824,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   const int lane = threadIdx.x;
   const cfloat_p tD = (cfloat_p)p.D, tB = (cfloat_p)p.B, tU = (cfloat_p)p.U, tRR = (cfloat_p)p.RR;
   const cfloat_p tPi = (cfloat_p)p.pi, tCR = (cfloat_p)p.cR, tExpT = (cfloat_p)p.expT;
+  const Tables tabs = {tD, tB, tU, tRR, (cfloat_p)p.rowSets, tCR, KP};
   const cint_p tStepRow = (cint_p)p.stepRow;
   const cint_p tRowGapF = (cint_p)p.rowGapF, tRowSiteB = (cint_p)(SEQ ? p.rowSiteB : p.stepRow),
                tRowGapB = (cint_p)p.rowGapB;
@@ -613,8 +938,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     // previous half-step left in the ring), then the half-step towards pos-1 unless pos is the window start.
     auto betaGapStep = [&](float (&b)[KA], const int q, const EmisRegs& rows) {
       commitEmis(q, rows);
-      const size_t row = (size_t)tRowGapB[q] * KP;
-      beta_step<KT, KA, false>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][3 * E4], cycW);
+      const int row = tRowGapB[q];
+      beta_step<KT, KA, false>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW);
     };
     auto betaSeqStep = [&](float (&b)[KA], const int pos) {
       const int q = pos + 1;
@@ -624,8 +949,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         ev = prefetchEmis(pos);
       }
       const int c = obsClass(q);
-      const size_t row = (size_t)tRowSiteB[q] * KP;
-      beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
+      const int row = tRowSiteB[q];
+      beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
       if (gap) {
         betaGapStep(b, pos, ev);
       }
@@ -672,8 +997,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             ev = prefetchEmis(q - 1);
           }
           const int c = obsClass(q);
-          const size_t row = (size_t)tStepRow[q] * KP;
-          beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
+          const int row = tStepRow[q];
+          beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
           afterBeta(pos);
         }
       }
@@ -758,8 +1083,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
                 ev = prefetchEmis(q - 1);
               }
               const int c = obsClass(q);
-              const size_t row = (size_t)tStepRow[q] * KP;
-              beta_step<KT, KA>(K, b, w, tD + row, tB + row, tU + row, tRR + row, &emisLds[q & 1][c * E4], cycW);
+              const int row = tStepRow[q];
+              beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
               const int rel = pos - lo;
               if (!HALF || (rel & 1) || pos == hi - 1) {
                 store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4 + lane, b);
@@ -820,16 +1145,16 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         if (pos == from) {
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
-          const size_t row = (size_t)tStepRow[pos] * KP;
-          alpha_step<KT, KA>(K, a, w, tD + row, tB + row, tU + row, tCR, e, cycW);
+          const int row = tStepRow[pos];
+          alpha_step<KT, KA>(K, a, w, tabs, row, e, cycW);
         }
         if constexpr (SEQ) {
           // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step
           // across the gap to the next site (HMM.cpp:764-767); the last site of the window keeps its alpha
           if (pos < to - 1) {
             commitEmis(pos + 1, ev);
-            const size_t row = (size_t)tRowGapF[pos + 1] * KP;
-            alpha_step<KT, KA, false>(K, a, w, tD + row, tB + row, tU + row, tCR, &emisLds[(pos + 1) & 1][3 * E4],
+            const int row = tRowGapF[pos + 1];
+            alpha_step<KT, KA, false>(K, a, w, tabs, row, &emisLds[(pos + 1) & 1][3 * E4],
                                       cycW);
           }
         }
@@ -852,8 +1177,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           }
           const int q = pos + 1;
           const int cq1 = obsClass(q);
-          const size_t rowq = (size_t)tStepRow[q] * KP;
-          beta_step<KT, KA>(K, b, w, tD + rowq, tB + rowq, tU + rowq, tRR + rowq, &emisLds[q & 1][cq1 * E4], cycW);
+          const int rowq = tStepRow[q];
+          beta_step<KT, KA>(K, b, w, tabs, rowq, &emisLds[q & 1][cq1 * E4], cycW);
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             w[k] = a[k] * b[k];
