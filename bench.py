@@ -28,14 +28,15 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); ~6.3e12 is the measured achievable
 
 
-def measured_traffic(n_hap: int, n_sites: int, K: int):
+def measured_traffic(n_hap: int, n_sites: int, K: int, beta_stride: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction).
-    PMC collection cannot run inside the timed process, so the figure is the committed measurement; it is
-    reported only for the workload it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if (n_hap, n_sites, K) != (1000, 50000, 69) or not os.path.exists(path):
+    (profiles/r01b_traffic.json for beta stride 2, profiles/r01_traffic.json for stride 1: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction).  PMC collection cannot run inside the timed process, so the
+    figure is the committed measurement; it is reported only for the workload and kernel it was measured on."""
+    name = {1: "r01_traffic.json", 2: "r01b_traffic.json"}.get(beta_stride)
+    if (n_hap, n_sites, K) != (1000, 50000, 69) or name is None:
         return None
+    path = os.path.join(ROOT, "profiles", name)
     try:
         return float(json.load(open(path))["hbm_bytes_per_launch"])
     except Exception:
@@ -213,7 +214,7 @@ def main() -> None:
                        **({"DIAGNOSTIC_same_row": True} if args.diag_same_row else {}),
                        **({"phase_cycles": [int(x) for x in phase]} if phase.any() else {})},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": measured_traffic(args.haps, args.sites, pm.K),
+                         "frac": achieved / HBM_PEAK, "traffic": measured_traffic(args.haps, args.sites, pm.K, ctx.last_beta_stride()),
                          "kernel_ms": 1e3 * k_s, "algorithmic_bytes_per_launch": algo_bytes},
         }
         if args.cpu_pairs > 0 and world == 1:

@@ -73,7 +73,6 @@ struct fsmc_model {
   int K = 0, KP = 0, S = 0, nRows = 0;
   float *pi = nullptr, *cR = nullptr, *expT = nullptr;
   float *D = nullptr, *B = nullptr, *U = nullptr, *RR = nullptr;
-  float *laneB = nullptr, *laneA = nullptr; // [rows][NT*64] LaneTab records of the compile-time-K kernels
   float* rowSets = nullptr; // [rows][5][KP]: D | B | U | Ush | RR per key, Ush[k] = U[k-1] (kernels' RowSet)
   int* stepRow = nullptr;
   bool sequence = false;
@@ -309,8 +308,6 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.B = m->B;
   p.U = m->U;
   p.rowSets = m->rowSets;
-  p.laneB = m->laneB;
-  p.laneA = m->laneA;
   p.RR = m->RR;
   p.stepRow = m->stepRow;
   p.rowGapF = m->rowGapF;
@@ -577,26 +574,6 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
     }
     rc = upload(ctx, &m->rowSets, rs.data(), rs.size());
   }
-  if (rc == FSMC_OK && K == 69) {
-    // LaneTab records (fsmc_kernels.h): the four rows a step needs, flat [4][K], padded to whole 64-lane registers
-    const size_t n = (size_t)d->n_rows;
-    const size_t rec = (size_t)((4 * K + kWave - 1) / kWave) * kWave;
-    std::vector<float> lb(n * rec, 0.f), la(n * rec, 0.f);
-    for (size_t r = 0; r < n; ++r) {
-      for (int k = 0; k < K; ++k) {
-        lb[r * rec + k] = la[r * rec + k] = d->D[r * K + k];
-        lb[r * rec + K + k] = la[r * rec + K + k] = d->B[r * K + k];
-        lb[r * rec + 2 * K + k] = k >= 1 ? d->U[r * K + (k - 1)] : 0.f;
-        la[r * rec + 2 * K + k] = d->U[r * K + k];
-        lb[r * rec + 3 * K + k] = d->RR[r * K + k];
-        la[r * rec + 3 * K + k] = d->col_ratios[k];
-      }
-    }
-    rc = upload(ctx, &m->laneB, lb.data(), lb.size());
-    if (rc == FSMC_OK) {
-      rc = upload(ctx, &m->laneA, la.data(), la.size());
-    }
-  }
   m->sequence = seq;
   auto upRows = [&](int** dst, const int32_t* src) {
     if (rc == FSMC_OK) {
@@ -662,7 +639,7 @@ void fsmc_model_destroy(fsmc_model* m)
       m->ctx->ibdModel = nullptr;
     }
   }
-  float* ptrs[] = {m->pi, m->cR, m->expT, m->D, m->B, m->U, m->rowSets, m->laneB, m->laneA, m->RR, (float*)m->emis3};
+  float* ptrs[] = {m->pi, m->cR, m->expT, m->D, m->B, m->U, m->rowSets, m->RR, (float*)m->emis3};
   for (float* q : ptrs) {
     if (q) (void)hipFree(q);
   }

@@ -56,8 +56,6 @@ struct KParams {
   const float* D;     // [rows][KP]
   const float* B;
   const float* U;
-  const float* laneB;   // [rows][NT*64] backward LaneTab records (D | B | Ush | RR), compile-time K only
-  const float* laneA;   // [rows][NT*64] forward LaneTab records (D | B | U | columnRatios)
   const float* rowSets; // [rows][5][KP]: D | B | U | Ush | RR of one key side by side, Ush[k] = U[k-1] (packed steps)
   const float* RR;
   const int* stepRow; // [S] row of the step into site q (array mode); sequence mode: the site step, forward
@@ -449,9 +447,17 @@ __device__ __forceinline__ void alpha_step_1(const int K, float (&a)[KA], float 
 //
 // Backward: the term U[k]*vec[k+1] of BU[k] is taken from T[m] = Ush[m]*vec[m] with Ush[m] = U[m-1]
 // (a second copy of the U table shifted by one state), so that both factors share a state index.
+// First operand block of a backward step, requested by the step before it (BetaHead): the descending pass opens
+// with a wait on operands that nothing can be overlapped with unless they were asked for during the previous step's
+// last block.  The previous step waits for them before it returns (after its scaling loop), so the values are final
+// when they cross the code between two steps.
+struct BetaHead {
+  typename SV<kKB>::T u, rr;
+};
+
 template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfloat_p rowSet, const float4* e,
-                                             long long& waitCycles)
+                                             long long& waitCycles, BetaHead& head, cfloat_p nextRowSet)
 {
   constexpr int K = KT;
   // the five table rows of one key sit side by side (RowSet): one base register, block offsets as immediates
@@ -460,19 +466,9 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
   constexpr int NB = (K + kKB - 1) / kKB; // operand blocks (scalar loads, one block ahead)
   constexpr int R = kKB / 8;              // emission sub-blocks of 8 states per operand block
   constexpr int NSB = (K + 7) / 8;
-  SVec u = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (NB - 1) * kKB);
-  SVec rr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (NB - 1) * kKB);
+  static_assert(!kTouch || (KPc == 80 && K > 64), "line warm-up is laid out for rows of five 64-byte lines");
+  SVec u = head.u, rr = head.rr; // requested and waited for by betaHeadPrime or by the previous step
   Touched tu, trr, td, tbt;
-  if constexpr (kTouch) {
-    static_assert(!kTouch || (KPc == 80 && K > 64), "line warm-up is laid out for rows of five 64-byte lines");
-    touchLines<0>(tu, rowSet, kRowUsh * KPc);
-    touchLines<0>(trr, rowSet, kRowRR * KPc);
-    if constexpr (kTouchAll) {
-      // the ascending pass's rows too: one exposed miss per step instead of one per pass
-      touchLines<0>(td, rowSet, kRowD * KPc);
-      touchLines<1>(tbt, rowSet, kRowB * KPc);
-    }
-  }
   SVec nu = u, nrr = rr;
   EmisBlk<8> em = readEmis<8>(e, NSB - 1);
   SVec d, bt;
@@ -487,16 +483,6 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
         FSMC_SWAIT(waitCycles, nu, nrr);
         u = nu;
         rr = nrr;
-      } else {
-        FSMC_SWAIT(waitCycles, u, rr);
-        if constexpr (kTouch) {
-          holdTouched(tu);
-          holdTouched(trr);
-          if constexpr (kTouchAll) {
-            holdTouched(td);
-            holdTouched(tbt);
-          }
-        }
       }
       if (blk > 0) {
         nu = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (blk - 1) * kKB);
@@ -504,7 +490,7 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
       } else {
         d = SV<kKB>::loadAt(rowSet, kRowD * KPc);
         bt = SV<kKB>::loadAt(rowSet, kRowB * KPc);
-        if constexpr (kTouch && !kTouchAll) {
+        if constexpr (kTouch) {
           touchLines<1>(td, rowSet, kRowD * KPc);
           touchLines<1>(tbt, rowSet, kRowB * KPc);
         }
@@ -561,7 +547,7 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
       bt = nbt;
     } else {
       FSMC_SWAIT(waitCycles, d, bt);
-      if constexpr (kTouch && !kTouchAll) {
+      if constexpr (kTouch) {
         holdTouched(td);
         holdTouched(tbt);
       }
@@ -569,6 +555,15 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
     if (blk + 1 < NB) {
       nd = SV<kKB>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKB);
       nbt = SV<kKB>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKB);
+    } else {
+      // last block: the next step's first operand block and the lines of its descending pass (always requested --
+      // a branch here would split the step's single basic block; without a next step the caller passes this row)
+      head.u = SV<kKB>::loadAt(nextRowSet, kRowUsh * KPc + (NB - 1) * kKB);
+      head.rr = SV<kKB>::loadAt(nextRowSet, kRowRR * KPc + (NB - 1) * kKB);
+      if constexpr (kTouch) {
+        touchLines<0>(tu, nextRowSet, kRowUsh * KPc);
+        touchLines<0>(trr, nextRowSet, kRowRR * KPc);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -617,6 +612,30 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
     for (int k = 0; k < K; ++k) {
       b[k] = w[k];
     }
+  }
+  FSMC_SWAIT(waitCycles, head.u, head.rr);
+  if constexpr (kTouch) {
+    holdTouched(tu);
+    holdTouched(trr);
+  }
+}
+
+// The first operand block of a backward step that no step precedes (start of a sweep, a recomputed row).
+template <int KT> __device__ __forceinline__ void betaHeadPrime(BetaHead& head, cfloat_p rowSet, long long& waitCycles)
+{
+  constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
+  constexpr int NB = (KT + kKB - 1) / kKB;
+  head.u = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (NB - 1) * kKB);
+  head.rr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (NB - 1) * kKB);
+  Touched tu, trr;
+  if constexpr (kTouch) {
+    touchLines<0>(tu, rowSet, kRowUsh * KPc);
+    touchLines<0>(trr, rowSet, kRowRR * KPc);
+  }
+  FSMC_SWAIT(waitCycles, head.u, head.rr);
+  if constexpr (kTouch) {
+    holdTouched(tu);
+    holdTouched(trr);
   }
 }
 
@@ -745,273 +764,6 @@ __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cf
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Lane-resident operands.  Scalar loads return out of order, so a wave can only wait for all of them
-// (lgkmcnt(0)) and the operand stream above can never run more than one block ahead -- with table rows that mostly
-// miss the 16-KB scalar cache (16 waves share it, each at its own site) the steps spent more time parked in those
-// waits than issuing arithmetic.  Here the four table rows a step needs are one flat [4][K] record per key
-// (LaneTab: slot s lives in lane s % 64 of register s / 64); the wave fetches the record of the NEXT step with
-// NT coalesced dword loads while the current step runs (vector memory returns in order, so the wait is counted and
-// a whole step long), and each operand is moved into an SGPR by v_readlane_b32 right where it is used.  One more
-// VALU instruction per operand, no scalar-memory wait in the step.
-//   backward record: D | B | Ush | RR        forward record: D | B | U | columnRatios
-template <int KT> struct LaneTab {
-  static constexpr int NT = (4 * KT + kWave - 1) / kWave;
-  float r[NT];
-};
-template <int KT> __device__ __forceinline__ float laneOp(const LaneTab<KT>& t, const int slot)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.r[slot >> 6]), slot & 63));
-#else
-  return t.r[slot >> 6];
-#endif
-}
-template <int KT> __device__ __forceinline__ f32x2 lanePair(const LaneTab<KT>& t, const int slot)
-{
-  const f32x2 r = {laneOp(t, slot), laneOp(t, slot + 1)};
-  return r;
-}
-template <int KT> __device__ __forceinline__ LaneTab<KT> loadLaneTab(const float* __restrict__ base, const int key)
-{
-  LaneTab<KT> t;
-  const float* src = base + (size_t)key * (LaneTab<KT>::NT * kWave) + threadIdx.x;
-#pragma unroll
-  for (int j = 0; j < LaneTab<KT>::NT; ++j) {
-    t.r[j] = src[j * kWave];
-  }
-  return t;
-}
-
-// Operands of one block of 8 states, moved from the LaneTab into SGPRs one block before their use (a VALU
-// instruction that reads an SGPR written by the v_readlane just before it waits for that write; here the reads of
-// block i+1 are spread between the arithmetic of block i and cost nothing but their issue slot).
-template <int KT, int NTBL> struct LaneBlk {
-  float v[NTBL][8];
-};
-template <int KT, int NTBL>
-__device__ __forceinline__ void laneFetch(LaneBlk<KT, NTBL>& o, const LaneTab<KT>& t, const int (&part)[NTBL],
-                                          const int blk, const int i)
-{
-  // states blk*8 + i and blk*8 + i + 1 of every table of the block
-#pragma unroll
-  for (int tb = 0; tb < NTBL; ++tb) {
-#pragma unroll
-    for (int ii = i; ii < i + 2; ++ii) {
-      const int k = blk * 8 + ii;
-      o.v[tb][ii] = (k < KT) ? laneOp(t, part[tb] * KT + k) : 0.f;
-    }
-  }
-}
-
-template <int KT, int KA, bool SCALE = true>
-__device__ __forceinline__ void beta_step_ln(float (&b)[KA], float (&w)[KA], const LaneTab<KT>& t, const float4* e)
-{
-  constexpr int K = KT;
-  constexpr int NB = (K + 7) / 8;
-  const int pDesc[2] = {2, 3}; // Ush, RR
-  const int pAsc[2] = {0, 1};  // D, B
-  EmisBlk<8> em = readEmis<8>(e, NB - 1);
-  LaneBlk<KT, 2> op, opn;
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    laneFetch<KT, 2>(op, t, pDesc, NB - 1, i);
-  }
-  float tNext = 0.f; // T[k+1] = U[k]*vec[k+1] of the state above the one the chain is at
-#pragma unroll
-  for (int blk = NB - 1; blk >= 0; --blk) {
-    EmisBlk<8> nem = em;
-    if (blk > 0) {
-      nem = readEmis<8>(e, blk - 1);
-    }
-#pragma unroll
-    for (int i = 6; i >= 0; i -= 2) {
-      const int k = blk * 8 + i;
-      if (blk > 0) {
-        laneFetch<KT, 2>(opn, t, pDesc, blk - 1, i);
-      } else {
-        laneFetch<KT, 2>(opn, t, pAsc, 0, i);
-      }
-      if (k + 1 < K) {
-        f32x2 v = {b[k], b[k + 1]};
-        v = v * em.pair(i);
-        const f32x2 u2 = {op.v[0][i], op.v[0][i + 1]};
-        const f32x2 T = u2 * v;
-        b[k] = v.x;
-        b[k + 1] = v.y;
-        // BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1], BU[K-1] = 0 (HMM.cpp:986-1005)
-        w[k + 1] = (k + 1 == K - 1) ? 0.f : tNext + op.v[1][i + 1] * w[k + 2];
-        w[k] = T.y + op.v[1][i] * w[k + 1];
-        tNext = T.x;
-      } else if (k < K) {
-        b[k] = b[k] * em.at(i);
-        tNext = op.v[0][i] * b[k];
-        w[k] = 0.f;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    op = opn;
-    em = nem;
-  }
-  // ascending: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k]
-  float BL = 0.f;
-  float sum = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      const int k = blk * 8 + i;
-      if (blk + 1 < NB) {
-        laneFetch<KT, 2>(opn, t, pAsc, blk + 1, i);
-      }
-      if (k + 1 < K) {
-        const f32x2 v = {b[k], b[k + 1]};
-        const f32x2 d2 = {op.v[0][i], op.v[0][i + 1]};
-        const f32x2 b2 = {op.v[1][i], op.v[1][i + 1]};
-        const f32x2 dv = d2 * v;
-        const f32x2 bv = b2 * v;
-        f32x2 bl;
-        bl.x = BL;
-        bl.y = BL + bv.x;
-        f32x2 x = bl + dv;
-        const f32x2 bu = {w[k], w[k + 1]};
-        x = x + bu;
-        w[k] = x.x;
-        w[k + 1] = x.y;
-        sum = sum + x.x;
-        sum = sum + x.y;
-        BL = (k + 1 < K - 1) ? bl.y + bv.y : bl.y;
-      } else if (k < K) {
-        w[k] = (BL + op.v[0][i] * b[k]) + w[k];
-        sum = sum + w[k];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    op = opn;
-  }
-  if constexpr (SCALE) {
-    const float c = 1.0f / sum;
-    const f32x2 cc = {c, c};
-#pragma unroll
-    for (int k = 0; k < K; k += 2) {
-      if (k + 1 < K) {
-        const f32x2 x = {w[k], w[k + 1]};
-        const f32x2 y = x * cc;
-        b[k] = y.x;
-        b[k + 1] = y.y;
-      } else {
-        b[k] = w[k] * c;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      b[k] = w[k];
-    }
-  }
-}
-
-template <int KT, int KA, bool SCALE = true>
-__device__ __forceinline__ void alpha_step_ln(float (&a)[KA], float (&w)[KA], const LaneTab<KT>& t, const float4* e)
-{
-  constexpr int K = KT;
-  static_assert(K >= 2, "packed step needs at least two states");
-  constexpr int NB = (K + 7) / 8;
-  const int parts[4] = {0, 1, 2, 3}; // D, B, U, columnRatios
-  EmisBlk<8> em = readEmis<8>(e, 0);
-  LaneBlk<KT, 4> op, opn;
-  // suffix sums one slot down: w[k] = alphaC[k+1] (HMM.cpp:799-814); the first block's operands come over meanwhile
-  w[K - 2] = a[K - 1];
-#pragma unroll
-  for (int k = K - 2; k >= 1; --k) {
-    w[k - 1] = w[k] + a[k];
-    if (k <= 8 && (k & 1) == 0) {
-      laneFetch<KT, 4>(op, t, parts, 0, 8 - k);
-    }
-  }
-  float AU = 0.f;
-  float sum = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
-    EmisBlk<8> nem = em;
-    if (blk + 1 < NB) {
-      nem = readEmis<8>(e, blk + 1);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      const int k = blk * 8 + i;
-      if (blk + 1 < NB) {
-        laneFetch<KT, 4>(opn, t, parts, blk + 1, i);
-      }
-      if (k + 1 < K - 1) {
-        const f32x2 av = {a[k], a[k + 1]};
-        const f32x2 d2 = {op.v[0][i], op.v[0][i + 1]};
-        const f32x2 b2 = {op.v[1][i], op.v[1][i + 1]};
-        const f32x2 u2 = {op.v[2][i], op.v[2][i + 1]};
-        const f32x2 da = d2 * av;
-        const f32x2 ua = u2 * av;
-        const f32x2 ac = {w[k], w[k + 1]};
-        const f32x2 bw = b2 * ac;
-        f32x2 au;
-        au.x = AU;
-        au.y = ua.x + op.v[3][i] * AU; // AU of state k+1
-        f32x2 term = au + da;
-        term = term + bw;
-        const f32x2 o = em.pair(i) * term;
-        w[k] = o.x;
-        w[k + 1] = o.y;
-        sum = sum + o.x;
-        sum = sum + o.y;
-        AU = ua.y + op.v[3][i + 1] * au.y; // AU of state k+2
-      } else {
-#pragma unroll
-        for (int ii = i; ii < i + 2; ++ii) {
-          const int kk = blk * 8 + ii;
-          if (kk < K) {
-            float term = AU + op.v[0][ii] * a[kk];
-            if (kk < K - 1) {
-              term = term + op.v[1][ii] * w[kk];
-            }
-            w[kk] = em.at(ii) * term;
-            sum = sum + w[kk];
-            if (kk < K - 1) {
-              AU = op.v[2][ii] * a[kk] + op.v[3][ii] * AU;
-            }
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    op = opn;
-    em = nem;
-  }
-  if constexpr (SCALE) {
-    const float c = 1.0f / sum;
-    const f32x2 cc = {c, c};
-#pragma unroll
-    for (int k = 0; k < K; k += 2) {
-      if (k + 1 < K) {
-        const f32x2 x = {w[k], w[k + 1]};
-        const f32x2 y = x * cc;
-        a[k] = y.x;
-        a[k + 1] = y.y;
-      } else {
-        a[k] = w[k] * c;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      a[k] = w[k];
-    }
-  }
-}
-
-#if defined(FSMC_LANE_OPS)
-constexpr bool kLaneOps = true;
-#else
-constexpr bool kLaneOps = false; // measured on C2: 8 % slower than the scalar-load stream (the extra readlanes cost more than the waits)
-#endif
 
 #if defined(FSMC_NO_PK)
 constexpr bool kPacked = false;
@@ -1026,13 +778,21 @@ struct Tables {
   int KP;
 };
 
+// nextRow: key of the backward step that follows immediately (its first operands are requested ahead through
+// `head`), or -1.
 template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], const Tables& t, const int row,
-                                          const float4* e, long long& waitCycles)
+                                          const float4* e, long long& waitCycles, BetaHead& head,
+                                          const bool primed = false, const int nextRow = -1)
 {
   if constexpr (KT > 0 && kPacked) {
     constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
-    beta_step_pk<KT, KA, SCALE>(b, w, t.rowSets + (size_t)row * (kRowSetParts * KPc), e, waitCycles);
+    const cfloat_p rs = t.rowSets + (size_t)row * (kRowSetParts * KPc);
+    if (!primed) {
+      betaHeadPrime<KT>(head, rs, waitCycles);
+    }
+    beta_step_pk<KT, KA, SCALE>(b, w, rs, e, waitCycles, head,
+                                t.rowSets + (size_t)(nextRow < 0 ? row : nextRow) * (kRowSetParts * KPc));
   } else {
     const size_t o = (size_t)row * t.KP;
     beta_step_1<KT, KA, SCALE>(K, b, w, t.D + o, t.B + o, t.U + o, t.RR + o, e, waitCycles);
@@ -1209,15 +969,6 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   float4* const spsMem = saveS + threadIdx.x;
   // chunk-buffer slot of the row stored for the site at offset rel of its chunk
   auto slotOf = [](const int rel) -> size_t { return (size_t)(HALF ? (rel >> 1) : rel); };
-  // lane-resident operands (array mode, compile-time K): the table record of a step is fetched one step ahead
-  constexpr bool LANE = KT > 0 && !SEQ && kLaneOps;
-  typedef LaneTab<(LANE ? KT : 1)> Tab;
-  auto tabB = [&](const int q) -> Tab { // record of the beta step out of site q
-    return loadLaneTab<(LANE ? KT : 1)>(p.laneB, tStepRow[q]);
-  };
-  auto tabA = [&](const int q) -> Tab { // record of the alpha step into site q
-    return loadLaneTab<(LANE ? KT : 1)>(p.laneA, tStepRow[q]);
-  };
 
   struct EmisRegs {
     float4 v[NL];
@@ -1319,7 +1070,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     auto betaGapStep = [&](float (&b)[KA], const int q, const EmisRegs& rows) {
       commitEmis(q, rows);
       const int row = tRowGapB[q];
-      beta_step<KT, KA, false>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW);
+      BetaHead head;
+      beta_step<KT, KA, false>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW, head);
     };
     auto betaSeqStep = [&](float (&b)[KA], const int pos) {
       const int q = pos + 1;
@@ -1330,7 +1082,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       }
       const int c = obsClass(q);
       const int row = tRowSiteB[q];
-      beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+      BetaHead head;
+      beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW, head);
       if (gap) {
         betaGapStep(b, pos, ev);
       }
@@ -1367,27 +1120,25 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
       } else {
         EmisRegs ev;
-        Tab tb = {};
+        int rowNext = 0;
         if (to - 2 >= from) {
           ev = prefetchEmis(to - 1);
-          if constexpr (LANE) tb = tabB(to - 1);
+          rowNext = tStepRow[to - 1];
         }
+        BetaHead head;
+        bool primed = false;
         for (int pos = to - 2; pos >= from; --pos) {
           const int q = pos + 1;
           commitEmis(q, ev);
-          Tab tbn = tb;
+          const int row = rowNext;
+          rowNext = -1;
           if (pos - 1 >= from) {
             ev = prefetchEmis(q - 1);
-            if constexpr (LANE) tbn = tabB(q - 1);
+            rowNext = tStepRow[q - 1];
           }
           const int c = obsClass(q);
-          if constexpr (LANE) {
-            beta_step_ln<KT, KA>(b, w, tb, &emisLds[q & 1][c * E4]);
-          } else {
-            const int row = tStepRow[q];
-            beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
-          }
-          tb = tbn;
+          beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW, head, primed, rowNext);
+          primed = rowNext >= 0;
           afterBeta(pos);
         }
       }
@@ -1462,27 +1213,25 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
           } else {
             EmisRegs ev;
-            Tab tb = {};
+            int rowNext = 0;
             if (pos >= lo) {
               ev = prefetchEmis(pos + 1);
-              if constexpr (LANE) tb = tabB(pos + 1);
+              rowNext = tStepRow[pos + 1];
             }
+            BetaHead head;
+            bool primed = false;
             for (; pos >= lo; --pos) {
               const int q = pos + 1;
               commitEmis(q, ev);
-              Tab tbn = tb;
+              const int row = rowNext;
+              rowNext = -1;
               if (pos - 1 >= lo) {
                 ev = prefetchEmis(q - 1);
-                if constexpr (LANE) tbn = tabB(q - 1);
+                rowNext = tStepRow[q - 1];
               }
               const int c = obsClass(q);
-              if constexpr (LANE) {
-                beta_step_ln<KT, KA>(b, w, tb, &emisLds[q & 1][c * E4]);
-              } else {
-                const int row = tStepRow[q];
-                beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
-              }
-              tb = tbn;
+              beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW, head, primed, rowNext);
+              primed = rowNext >= 0;
               const int rel = pos - lo;
               if (!HALF || (rel & 1) || pos == hi - 1) {
                 store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4 + lane, b);
@@ -1510,30 +1259,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           ev2 = prefetchEmis(lo + 1);
         }
       }
-      // lane-resident operands: ta = record of the alpha step into this site, tr = record of the beta step that
-      // recomputes this site's row (HALF); both requested while the previous site is being worked on
-      Tab ta = {}, tr = {};
-      if constexpr (LANE) {
-        if (lo > from) {
-          ta = tabA(lo);
-        }
-        if (HALF && lo + 1 < hi) {
-          tr = tabB(lo + 1);
-        }
-      }
       for (int pos = lo; pos < hi; ++pos) {
         // HALF: this site's beta row was not stored -- it is recomputed below from the row of site pos+1
         const bool rec = HALF && ((pos - lo) & 1) == 0 && pos + 1 < hi;
-        Tab tan = ta, trn = tr;
-        if constexpr (LANE) {
-          if (pos + 1 < hi) {
-            tan = tabA(pos + 1);
-          }
-          // the site after next starts a pair of sites when this one ends one
-          if (HALF && !rec && pos + 2 < hi) {
-            trn = tabB(pos + 2);
-          }
-        }
+
         if constexpr (SEQ) {
           if (pos < to - 1) {
             ev = prefetchEmis(pos + 1);
@@ -1563,8 +1292,6 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         const float4* e = &emisLds[pos & 1][c * E4];
         if (pos == from) {
           alpha_init<KT, KA>(K, a, tPi, e);
-        } else if constexpr (LANE) {
-          alpha_step_ln<KT, KA>(a, w, ta, e);
         } else {
           const int row = tStepRow[pos];
           alpha_step<KT, KA>(K, a, w, tabs, row, e, cycW);
@@ -1598,12 +1325,9 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           }
           const int q = pos + 1;
           const int cq1 = obsClass(q);
-          if constexpr (LANE) {
-            beta_step_ln<KT, KA>(b, w, tr, &emisLds[q & 1][cq1 * E4]);
-          } else {
-            const int rowq = tStepRow[q];
-            beta_step<KT, KA>(K, b, w, tabs, rowq, &emisLds[q & 1][cq1 * E4], cycW);
-          }
+          const int rowq = tStepRow[q];
+          BetaHead head;
+          beta_step<KT, KA>(K, b, w, tabs, rowq, &emisLds[q & 1][cq1 * E4], cycW, head);
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             w[k] = a[k] * b[k];
@@ -1788,8 +1512,6 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
           }
         }
-        ta = tan;
-        tr = trn;
       }
       FSMC_STAMP(cycA);
     }
