@@ -84,8 +84,9 @@ def all_pairs(n_ind: int) -> np.ndarray:
 
 
 def cpu_baseline(pm, haps, n_pairs_sample: int, pairs: np.ndarray) -> dict:
-    """The oracle (C restatement of the reference's NO_SSE path, 1 thread) on the first pairs of the same
-    work list, same sites, reference batch size 32.  Reported baseline only."""
+    """The oracle (C restatement of the reference's NO_SSE path; here its -O3 -mavx2 build, which tests check is
+    bit-identical to the checker build) on the first pairs of the same work list, same sites, reference batch size
+    32, one batch per host thread on every core this process may use.  Reported baseline only."""
     from fastsmc_amd import synth
     from oracle import oracle as O
 
@@ -96,13 +97,22 @@ def cpu_baseline(pm, haps, n_pairs_sample: int, pairs: np.ndarray) -> dict:
                             gen=np.zeros(pm.S, np.float32), phys=np.zeros(pm.S, np.int32),
                             state_threshold=int(pm.state_threshold), age_threshold=int(pm.age_threshold),
                             probability_threshold=np.float32(pm.probability_threshold))
+    # one GPU's share of the host: at most 16 cores (each thread also holds two S x K x 32 float buffers)
+    cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
+    if n_pairs_sample <= 0:  # automatic: four batches of 32 pairs per core
+        n_pairs_sample = 4 * 32 * cores
     sample = [tuple(int(x) for x in pr) for pr in pairs[:n_pairs_sample]]
-    t0 = time.perf_counter()
-    recs = O.decode_pairs_ibd(model, folded, sample, batch_size=32)
-    dt = time.perf_counter() - t0
-    return {"value": len(sample) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": f"first {len(sample)} pairs of the same work list x {pm.S} sites (batches of 32), "
-                      f"{dt:.1f} s, {len(recs)} IBD records; oracle/hmm_oracle.c, gcc -O2, 1 thread"}
+    O.select_build("avx2")
+    try:
+        t0 = time.perf_counter()
+        recs = O.decode_pairs_ibd(model, folded, sample, batch_size=32, threads=cores)
+        dt = time.perf_counter() - t0
+    finally:
+        O.select_build("ref")
+    return {"value": len(sample) / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"first {len(sample)} pairs of the same work list x {pm.S} sites (batches of 32, one batch per "
+                      f"thread, {cores} threads), {dt:.1f} s wall, {len(recs)} IBD records; oracle/hmm_oracle.c, "
+                      f"gcc -O3 -mavx2 -ffp-contract=off"}
 
 
 def main() -> None:
@@ -120,7 +130,8 @@ def main() -> None:
     ap.add_argument("--diag-same-row", action="store_true",
                     help="diagnostic, NOT a result: every site uses the same transition-table row (scalar-cache hits)")
     ap.add_argument("--ws-frac", type=float, default=0.0, help="workspace cap as a fraction of HBM (0 = default)")
-    ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=-1,
+                    help="pairs in the cpu_baseline sample (0 = skip, -1 = automatic: 128 per host core)")
     args = ap.parse_args()
 
     import torch
@@ -217,7 +228,7 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK, "traffic": measured_traffic(args.haps, args.sites, pm.K, ctx.last_beta_stride()),
                          "kernel_ms": 1e3 * k_s, "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if args.cpu_pairs > 0 and world == 1:
+        if args.cpu_pairs != 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(pm, haps, args.cpu_pairs, pairs)
         else:
             out["cpu_baseline"] = None

@@ -17,13 +17,25 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_LIB_PATHS = {"ref": _LIB_PATH, "avx2": os.path.join(_HERE, "liboracle_avx2.so")}
+_variant = "ref"
+_libs: dict = {}
 
 
 def build(force: bool = False) -> str:
-    """Compile the C restatement (gcc; see oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH):
+    """Compile the C restatement (gcc; see oracle/Makefile): liboracle.so (-O2, the checker) and
+    liboracle_avx2.so (-O3 -mavx2, same sources; only bench.py's cpu_baseline times it)."""
+    if force or not all(os.path.exists(q) for q in _LIB_PATHS.values()):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
+
+
+def select_build(name: str) -> None:
+    """Which build lib() hands out: "ref" (default, the parity checker) or "avx2" (timing only)."""
+    global _variant, _lib
+    assert name in _LIB_PATHS
+    _variant = name
+    _lib = _libs.get(name)
 
 
 class _FoModel(C.Structure):
@@ -55,7 +67,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(_LIB_PATHS[_variant])
         L.fo_round_morgans.restype = C.c_float
         L.fo_round_morgans.argtypes = [C.c_float, C.c_int, C.c_float]
         L.fo_round_physical.restype = C.c_int
@@ -94,6 +106,7 @@ def lib():
         L.fo_undistinguished_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_void_p]
         _lib = L
+        _libs[_variant] = L
     return _lib
 
 
@@ -360,15 +373,20 @@ def rec_rate_at_marker(gen: np.ndarray, phys: np.ndarray) -> np.ndarray:
 # ------------------------------------------------------------ the hot path
 
 def decode_batch(model: PreparedModel, obs_bits: np.ndarray, hom_bits: np.ndarray, frm: int, to: int,
-                 want_alpha_fwd: bool = False):
+                 want_alpha_fwd: bool = False, buffers=None):
     """HMM::decodeBatch. obs_bits/hom_bits: [B][to-frm] uint8. Returns (posterior, beta[, alphaFwd]) with the
-    reference layout [S][K][B]; only rows [frm, to) are meaningful."""
+    reference layout [S][K][B]; only rows [frm, to) are meaningful.  buffers: optional (alpha, beta) arrays of
+    that shape to decode into (the reference reuses its m_alphaBuffer / m_betaBuffer from batch to batch too)."""
     ob = np.ascontiguousarray(obs_bits, np.uint8)
     hb = np.ascontiguousarray(hom_bits, np.uint8)
     B = ob.shape[0]
     assert ob.shape == hb.shape == (B, to - frm)
-    alpha = np.zeros((model.S, model.K, B), np.float32)
-    beta = np.zeros((model.S, model.K, B), np.float32)
+    if buffers is not None:
+        alpha, beta = buffers
+        assert alpha.shape == beta.shape == (model.S, model.K, B) and alpha.dtype == beta.dtype == np.float32
+    else:
+        alpha = np.zeros((model.S, model.K, B), np.float32)
+        beta = np.zeros((model.S, model.K, B), np.float32)
     afwd = np.zeros((model.S, model.K, B), np.float32) if want_alpha_fwd else None
     m = model.c_struct()
     lib().fo_decode_batch(C.byref(m), _p(ob), _p(hb), B, frm, to, _p(alpha), _p(beta), _p(afwd))
@@ -433,13 +451,18 @@ def enumerate_all_pairs(n_ind: int, jobs: int = 1, job_ind: int = 1, within_only
 
 
 def decode_pairs_ibd(model: PreparedModel, hap_bytes: np.ndarray, pairs, *, batch_size=32, want_mean=True,
-                     want_map=True, sums=None):
+                     want_map=True, sums=None, threads: int = 1):
     """Non-hashing FastSMC-mode decode of a pair list: addToBatch/runLastBatch with whole-sequence windows
     (HMM.cpp:555-636), then writePerPairOutputFastSMC per batch.  hap_bytes: [n_hap][S] uint8 folded alleles.
-    Returns IBD records in the reference's output order (batch, pair in batch, site)."""
+    Returns IBD records in the reference's output order (batch, pair in batch, site).  threads > 1 decodes
+    batches concurrently (the C calls release the GIL; batches are independent) -- the reference itself is
+    single-threaded, this is only how the CPU baseline uses all host cores."""
     S = model.S
-    recs = []
-    for b0 in range(0, len(pairs), batch_size):
+    import threading
+
+    tls = threading.local()
+
+    def one_batch(b0: int):
         chunk = pairs[b0:b0 + batch_size]
         actual = len(chunk)
         padded = list(chunk)
@@ -447,12 +470,25 @@ def decode_pairs_ibd(model: PreparedModel, hap_bytes: np.ndarray, pairs, *, batc
             padded.append(padded[-1])
         ob = np.stack([hap_bytes[a] ^ hap_bytes[b] for a, b in padded])
         hb = np.stack([hap_bytes[a] & hap_bytes[b] for a, b in padded])
-        post, _ = decode_batch(model, ob, hb, 0, S)
+        bufs = getattr(tls, "bufs", None)  # one alpha/beta buffer pair per thread, like the reference's members
+        if bufs is None or bufs[0].shape[2] != len(padded):
+            bufs = (np.zeros((S, model.K, len(padded)), np.float32), np.zeros((S, model.K, len(padded)), np.float32))
+            tls.bufs = bufs
+        post, _ = decode_batch(model, ob, hb, 0, S, buffers=bufs)
         if sums is not None:
             augment_sum_over_pairs(model, post, actual, ob, hb, sums)
-        for v in range(actual):
-            recs.append(ibd_scan_pair(model, post, v, 0, S, want_mean=want_mean, want_map=want_map,
-                                      pair_ordinal=b0 + v))
+        return [ibd_scan_pair(model, post, v, 0, S, want_mean=want_mean, want_map=want_map, pair_ordinal=b0 + v)
+                for v in range(actual)]
+
+    starts = range(0, len(pairs), batch_size)
+    if threads > 1 and sums is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            per_batch = list(ex.map(one_batch, starts))
+    else:
+        per_batch = [one_batch(b0) for b0 in starts]
+    recs = [r for batch in per_batch for r in batch]
     return np.concatenate(recs) if recs else np.zeros(0, IBD_DTYPE)
 
 
