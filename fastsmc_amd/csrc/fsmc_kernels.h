@@ -150,7 +150,7 @@ __device__ __forceinline__ void touchLines(Touched& t, cfloat_p p, const int fir
 {
   // lines FIRST, FIRST+1, ... (up to four) of the row that starts at state firstState; STEP = floats per line
   FSMC_GCN_ASM("s_load_dword %0, %4, %5\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %4, %7\n\ts_load_dword %3, %4, %8"
-               : "=s"(t.r[0]), "=s"(t.r[1]), "=s"(t.r[2]), "=s"(t.r[3])
+               : "=&s"(t.r[0]), "=&s"(t.r[1]), "=&s"(t.r[2]), "=&s"(t.r[3]) // early clobber: never the address pair
                : "s"(p), "i"((firstState + FIRST * STEP) * 4), "i"((firstState + (FIRST + 1) * STEP) * 4),
                  "i"((firstState + (FIRST + 2) * STEP) * 4), "i"((firstState + (FIRST + 3) * STEP) * 4));
 }
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   constexpr int NL = (NC * E4A + kWave - 1) / kWave;      // float4 per lane to stage one site's rows
   const int K = KT > 0 ? KT : p.K;
   const int K4 = (K + 3) >> 2;
-  const int KP = p.KP;
+  const int KP = p.KP; // (a compile-time KP for fixed K measured 6 % slower on C2: keep the runtime value)
   const int E4 = KP >> 2;
 
   __shared__ float4 emisLds[2][NC * E4A]; // ring of two sites x three observation classes (+ the gap row)
@@ -1329,9 +1329,24 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           BetaHead head;
           beta_step<KT, KA>(K, b, w, tabs, rowq, &emisLds[q & 1][cq1 * E4], cycW, head);
 #pragma unroll
-          for (int k = 0; k < K; ++k) {
-            w[k] = a[k] * b[k];
-            sumq = sumq + w[k];
+          for (int k = 0; k < K; k += 2) {
+            if (KT > 0 && k + 1 < K) { // products two states at a time, the sum in state order
+              const f32x2 av = {a[k], a[k + 1]};
+              const f32x2 bv = {b[k], b[k + 1]};
+              const f32x2 q = av * bv;
+              w[k] = q.x;
+              w[k + 1] = q.y;
+              sumq = sumq + q.x;
+              sumq = sumq + q.y;
+            } else {
+#pragma unroll
+              for (int kk = k; kk < k + 2; ++kk) {
+                if (kk < K) {
+                  w[kk] = a[kk] * b[kk];
+                  sumq = sumq + w[kk];
+                }
+              }
+            }
           }
         } else {
           constexpr int kCB = 8; // states per block of the combine
@@ -1352,11 +1367,25 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               loadB(blk + 1, n0, n1);
             }
 #pragma unroll
-            for (int i = 0; i < kCB; ++i) {
+            for (int i = 0; i < kCB; i += 2) {
               const int k = blk * kCB + i;
-              if (k < K) {
-                w[k] = a[k] * pick(c0, c1, i);
-                sumq = sumq + w[k];
+              if (KT > 0 && k + 1 < K) {
+                const f32x2 av = {a[k], a[k + 1]};
+                const f32x2 bv = {pick(c0, c1, i), pick(c0, c1, i + 1)};
+                const f32x2 q = av * bv;
+                w[k] = q.x;
+                w[k + 1] = q.y;
+                sumq = sumq + q.x;
+                sumq = sumq + q.y;
+              } else {
+#pragma unroll
+                for (int ii = i; ii < i + 2; ++ii) {
+                  const int kk = blk * kCB + ii;
+                  if (kk < K) {
+                    w[kk] = a[kk] * pick(c0, c1, ii);
+                    sumq = sumq + w[kk];
+                  }
+                }
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1452,7 +1481,9 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         if (MODE == kModeIbd) {
           if (pos >= scanFrom) {
             // posterior of the states the scan needs
-            const unsigned nPost = TRACK ? (p.ageThr > p.stateThr ? p.ageThr : p.stateThr) : p.stateThr;
+            // (the states beyond the scan's only feed the per-state sums of open segments: scaled there, by the
+            //  lanes that are inside a segment)
+            const unsigned nPost = p.stateThr;
             // (guards instead of early exits: a data-dependent trip count would turn the register
             //  arrays into dynamically indexed scratch memory)
 #pragma unroll
@@ -1491,10 +1522,12 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
                     if (!opening) {
                       sv = spsMem[(size_t)k4 * kWave];
                     }
-                    sv.x = sv.x + w[4 * k4];
-                    if (4 * k4 + 1 < K) sv.y = sv.y + w[4 * k4 + 1];
-                    if (4 * k4 + 2 < K) sv.z = sv.z + w[4 * k4 + 2];
-                    if (4 * k4 + 3 < K) sv.w = sv.w + w[4 * k4 + 3];
+                    // blocks the scan already normalised are taken as they are (x * 1.0f is exact)
+                    const float sc = ((unsigned)(4 * k4) < nPost) ? 1.0f : cq;
+                    sv.x = sv.x + w[4 * k4] * sc;
+                    if (4 * k4 + 1 < K) sv.y = sv.y + w[4 * k4 + 1] * sc;
+                    if (4 * k4 + 2 < K) sv.z = sv.z + w[4 * k4 + 2] * sc;
+                    if (4 * k4 + 3 < K) sv.w = sv.w + w[4 * k4 + 3] * sc;
                     spsMem[(size_t)k4 * kWave] = sv;
                   }
                 }
