@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Side measurements on one MI355X for the BASELINE.json configs that are not the bench line (reported in DESIGN.md,
+never as bench.py's `value`):
+  c1_ibd / c1_sums   300 haplotypes x 6760 sites, K = 69, all 44 850 pairs: IBD consumer, and the sum-over-pairs
+                     consumer of the reference's own published timing (time_regression.py: 51.97 s on one CPU thread)
+  k256               generic (runtime-K) kernel, K = 256, reduced C4 shape
+  hashing            FastSMC.run() end to end with the hashing pre-filter on, C2-sized files (parse + identify + decode +
+                     write), the C5 regime of many short windows
+Prints one JSON object per measurement.  Usage: python tools/measure_configs.py [c1 k256 hashing]"""
+from __future__ import annotations
+
+import copy
+import gzip
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from fastsmc_amd import api, capi, synth  # noqa: E402
+
+
+def prepared(n_hap, n_sites, K, seed=1234):
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(n_hap, n_sites, seed=seed)
+    data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
+    dq = api.decoding_quantities_from_tables(tables)
+    p = api.DecodingParams()
+    p.FastSMC = True
+    p.foldData = True
+    p.usingCSFS = True
+    p.batchSize = 32
+    p.time = 50
+    p.noConditionalAgeEstimates = True
+    p.doPerPairPosteriorMean = True
+    p.doPerPairMAP = True
+    p.outputIbdSegmentLength = True
+    p.useKnownSeed = True
+    p.hashing = False
+    hmm = api.HMM(data, dq, p)
+    return api.PreparedModelView(hmm.preparedModel()), data.packed_bits(), haps, tables
+
+
+def all_pairs(n_ind):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench.all_pairs(n_ind)
+
+
+def timed(fn, reps=2):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def c1():
+    pm, bits, _, _ = prepared(300, 6760, 69)
+    pairs = all_pairs(150)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    pr = pairs.view(capi.PAIR_DTYPE).reshape(-1)
+    ctx.upload_worklist(pr, capi.whole_sequence_groups(len(pr), pm.S, batch=64))
+    dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1])
+    print(json.dumps({"config": "c1_ibd", "pairs": len(pr), "sites": pm.S, "K": pm.K, "seconds": dt,
+                      "pairs_per_s": len(pr) / dt, "pair_sites_per_s": len(pr) * pm.S / dt, "kernel_ms": ctx.last_kernel_ms(),
+                      "records": int(rec.size)}))
+    dt, _ = timed(lambda: ctx.decode_sums(model))
+    print(json.dumps({"config": "c1_sums", "pairs": len(pr), "sites": pm.S, "K": pm.K, "seconds": dt,
+                      "pairs_per_s": len(pr) / dt, "pair_sites_per_s": len(pr) * pm.S / dt, "kernel_ms": ctx.last_kernel_ms(),
+                      "reference_published_s": 51.97}))
+    ctx.close()
+
+
+def k256():
+    pm, bits, _, _ = prepared(600, 3000, 256)  # 179 700 pairs = 2808 groups: every resident wave has work
+    pairs = all_pairs(300)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    pr = pairs.view(capi.PAIR_DTYPE).reshape(-1)
+    ctx.upload_worklist(pr, capi.whole_sequence_groups(len(pr), pm.S, batch=64))
+    dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1], reps=1)
+    print(json.dumps({"config": "k256_ibd", "pairs": len(pr), "sites": pm.S, "K": pm.K, "seconds": dt,
+                      "pairs_per_s": len(pr) / dt, "pair_sites_per_s": len(pr) * pm.S / dt, "kernel_ms": ctx.last_kernel_ms(),
+                      "algorithmic_GBps": len(pr) * pm.S * (8 * pm.K + 0.25) / dt / 1e9, "records": int(rec.size)}))
+    ctx.close()
+
+
+def hashing():
+    from oracle import oracle as O  # only for the table-key selection helper used by the tests as well
+
+    n_hap, n_sites = 1000, 50000
+    tables = synth.make_model_tables(69)
+    haps = synth.make_haps(n_hap, n_sites, seed=1234)
+    with tempfile.TemporaryDirectory() as d:
+        root = os.path.join(d, "syn")
+        t0 = time.perf_counter()
+        synth.write_haps_files(root, haps)
+        gen = (haps.cm / 100.0).astype(np.float32)
+        used = np.unique(np.concatenate([[0.0], O.step_rows(tables.keys, gen)[1][1:]]))
+        t = copy.copy(tables)
+        sel = np.nonzero(np.isin(t.keys, used.astype(np.float32)))[0]
+        t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
+        synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
+        t_write = time.perf_counter() - t0
+        p = api.DecodingParams()
+        p.inFileRoot = root
+        p.decodingQuantFile = root + ".decodingQuantities.gz"
+        p.outFileRoot = os.path.join(d, "out")
+        p.decodingModeString = "array"
+        p.foldData = True
+        p.usingCSFS = True
+        p.batchSize = 32
+        p.recallThreshold = 3
+        p.min_m = 1.5
+        p.hashing = True
+        p.FastSMC = True
+        p.BIN_OUT = False
+        p.outputIbdSegmentLength = True
+        p.time = 50
+        p.noConditionalAgeEstimates = True
+        p.doPerPairMAP = True
+        p.doPerPairPosteriorMean = True
+        p.useKnownSeed = True
+        assert p.validateParamsFastSMC()
+        t0 = time.perf_counter()
+        f = api.FastSMC(p)
+        t_init = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        f.run()
+        t_run = time.perf_counter() - t0
+        n_lines = sum(1 for _ in gzip.open(p.outFileRoot + ".1.1.FastSMC.ibd.gz", "rt"))
+    print(json.dumps({"config": "hashing_c2_files", "haplotypes": n_hap, "sites": n_sites, "K": 69,
+                      "write_inputs_s": t_write, "construct_s": t_init, "run_s": t_run, "ibd_lines": n_lines,
+                      "all_pairs": n_hap * (n_hap - 1) // 2 + 0}))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["c1", "k256", "hashing"]
+    for w in what:
+        {"c1": c1, "k256": k256, "hashing": hashing}[w]()
