@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "fsmc_kernels.h"
+#include "fsmc_kernels_q4.h"
 
 using namespace fsmc;
 
@@ -195,8 +196,21 @@ bool halfAvailable(int mode, const fsmc_model* m)
   return mode == kModeIbd && !m->sequence && m->K == 69;
 }
 
+// The wide-model kernel (four lanes per pair, fsmc_kernels_q4.h): K = 256, array mode, IBD and dump consumers.
+bool quarterLanes(int mode, const fsmc_model* m)
+{
+  return m->K == kQ4K && !m->sequence && (mode == kModeIbd || mode == kModeDump);
+}
+
 KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
 {
+  if (quarterLanes(mode, m)) {
+    if (mode == kModeIbd) {
+      m->ctx->lastStride = 1;
+      return track ? decode_kernel_q4<kModeIbd, true> : decode_kernel_q4<kModeIbd, false>;
+    }
+    return decode_kernel_q4<kModeDump, false>;
+  }
   const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1;
   if (mode == kModeIbd) {
     m->ctx->lastStride = half ? 2 : 1;
@@ -222,8 +236,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   if (blocksPerCU > 8) {
     blocksPerCU = 8;
   }
+  const bool q4 = quarterLanes(mode, m); // a wave takes a quarter of a group and holds 64 states per lane
   size_t slots = (size_t)ctx->nCU * blocksPerCU;
-  slots = std::min(slots, ctx->nGroups);
+  slots = std::min(slots, q4 ? 4 * ctx->nGroups : ctx->nGroups);
   if (slots < 1) {
     slots = 1;
   }
@@ -232,7 +247,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     const size_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
     L = std::max<size_t>(L, aEnd - g.from);
   }
-  const size_t K4 = (size_t)(m->K + 3) / 4;
+  const size_t K4 = q4 ? (size_t)kQ4F4 : (size_t)(m->K + 3) / 4;
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes);
   size_t C, maxChunks;
@@ -861,6 +876,10 @@ int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_
   }
   FSMC_HIP(ctx, hipMemcpyAsync(ctx->aux.p, offsets.data(), offsets.size() * sizeof(size_t), hipMemcpyHostToDevice,
                                ctx->stream));
+  if (quarterLanes(kModeDump, m)) {
+    // quarters of a group that hold no pair are skipped by the kernel: their lanes must read as zero
+    FSMC_HIP(ctx, hipMemsetAsync(ctx->out.p, 0, total * sizeof(float), ctx->stream));
+  }
   KParams p;
   fillParams(ctx, m, plan, 0, p);
   p.dumpOut = (float*)ctx->out.p;
