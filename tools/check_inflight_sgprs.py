@@ -28,7 +28,7 @@ def all_sgprs(line: str):
 
 def check(path: str) -> int:
     txt = open(path).read()
-    parts = re.split(r"\n(_ZN4fsmc13decode_kernel\w+):[^\n]*\n", txt)
+    parts = re.split(r"\n(_ZN4fsmc\d+decode_kernel\w+):[^\n]*\n", txt)
     bad = 0
     for i in range(1, len(parts), 2):
         name, body = parts[i], parts[i + 1].split(".Lfunc_end")[0]

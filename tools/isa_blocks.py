@@ -8,7 +8,7 @@ import sys
 flt = sys.argv[1]
 mn = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 txt = open("/tmp/fsmc_isa.s").read()
-parts = re.split(r"\n(_ZN4fsmc13decode_kernel\w+):[^\n]*\n", txt)
+parts = re.split(r"\n(_ZN4fsmc\d+decode_kernel\w+):[^\n]*\n", txt)
 for i in range(1, len(parts), 2):
     if flt not in parts[i]:
         continue

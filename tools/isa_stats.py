@@ -23,7 +23,7 @@ flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
 subprocess.run(["hipcc", *flags, *extra, "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", out,
                 os.path.join(ROOT, "fastsmc_amd/csrc/fsmc_capi.hip")], check=True)
 txt = open(out).read()
-parts = re.split(r"\n(_ZN4fsmc13decode_kernel\w+):[^\n]*\n", txt)
+parts = re.split(r"\n(_ZN4fsmc\d+decode_kernel\w+):[^\n]*\n", txt)
 for i in range(1, len(parts), 2):
     name, body = parts[i], parts[i + 1].split(".Lfunc_end")[0]
     if flt not in name:
