@@ -788,11 +788,16 @@ __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w
   if constexpr (KT > 0 && kPacked) {
     constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
     const cfloat_p rs = t.rowSets + (size_t)row * (kRowSetParts * KPc);
+#if defined(FSMC_NO_HEAD)
+    betaHeadPrime<KT>(head, rs, waitCycles);
+    beta_step_pk<KT, KA, SCALE>(b, w, rs, e, waitCycles, head, rs);
+#else
     if (!primed) {
       betaHeadPrime<KT>(head, rs, waitCycles);
     }
     beta_step_pk<KT, KA, SCALE>(b, w, rs, e, waitCycles, head,
                                 t.rowSets + (size_t)(nextRow < 0 ? row : nextRow) * (kRowSetParts * KPc));
+#endif
   } else {
     const size_t o = (size_t)row * t.KP;
     beta_step_1<KT, KA, SCALE>(K, b, w, t.D + o, t.B + o, t.U + o, t.RR + o, e, waitCycles);

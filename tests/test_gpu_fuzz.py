@@ -1,0 +1,71 @@
+"""Seeded random work lists against the oracle, bit for bit: random group sizes (1..64 pairs), random decode windows,
+random scan windows inside them, random beta stride, chunk size and workspace limit, ages on or off.  Each case
+checks every field of every IBD record of every pair."""
+import numpy as np
+import pytest
+
+from fastsmc_amd import capi
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"), ("post_mean", "postMean"),
+          ("map", "map"))
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_worklists(small_problem, seed):
+    rng = np.random.default_rng(1000 + seed)
+    pm = small_problem["model"]
+    folded = small_problem["folded"]
+    S = pm.S
+    allp = O.enumerate_all_pairs(32)
+    n_groups = int(rng.integers(2, 7))
+    wins, first = [], 0
+    for _ in range(n_groups):
+        cnt = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64]))
+        frm = int(rng.integers(0, S - 2))
+        to = int(rng.integers(frm + 1, min(S, frm + int(rng.choice([1, 2, 3, 40, 200, S]))) + 1))
+        sfrm = int(rng.integers(frm, to))
+        sto = int(rng.integers(sfrm + 1, to + 1))
+        wins.append((first, cnt, frm, to, sfrm, sto))
+        first += cnt
+    start = int(rng.integers(0, len(allp) - first))
+    pairs = allp[start:start + first]
+    groups = np.zeros(len(wins), capi.GROUP_DTYPE)
+    for g, w in zip(groups, wins):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    want_mean, want_map = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    flags = (capi.FSMC_WANT_MEAN if want_mean else 0) | (capi.FSMC_WANT_MAP if want_map else 0)
+
+    ctx = capi.Context(0)
+    ctx.set_beta_stride(int(rng.choice([0, 1, 2])))
+    if rng.integers(0, 2):
+        ctx.set_workspace_limit(int(rng.choice([12, 24, 64])) << 20)
+        ctx.set_chunk_sites(int(rng.choice([0, 16, 32, 80])))
+    model = ctx.create_model(pm)
+    ctx.upload_haps(small_problem["bits"], S)
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    try:
+        got = ctx.decode_ibd(model, pr, groups, flags)
+    except capi.FsmcError as e:  # a random workspace limit may be too small for the longest window: not a parity case
+        ctx.close()
+        assert "workspace limit" in str(e)
+        pytest.skip(str(e))
+    ctx.close()
+
+    want = []
+    for first, cnt, frm, to, sfrm, sto in wins:
+        sub = pairs[first:first + cnt]
+        ob = np.stack([(folded[a] ^ folded[b])[frm:to] for a, b in sub])
+        hb = np.stack([(folded[a] & folded[b])[frm:to] for a, b in sub])
+        post, _ = O.decode_batch(pm, ob, hb, frm, to)
+        full = np.zeros((S, pm.K, cnt), np.float32)
+        full[frm:to] = post[frm:to]
+        for v in range(cnt):
+            want.append(O.ibd_scan_pair(pm, full, v, sfrm, sto, want_mean=want_mean, want_map=want_map,
+                                        pair_ordinal=first + v))
+    want = np.concatenate(want) if want else np.zeros(0, O.IBD_DTYPE)
+    assert got.size == want.size
+    for f_got, f_want in FIELDS:
+        np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f_got)
