@@ -386,6 +386,12 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
     FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   };
+  // the same while the 16 row stores issued AFTER the DMA requests may still be in flight (vector memory
+  // operations retire in order, so at most 16 outstanding means the older DMA requests are done)
+  auto landedBeforeRowStores = [&]() {
+    FSMC_GCN_ASM("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
   auto ldsReadsDone = [&]() {
     FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -555,9 +561,15 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
             stageEmis(pos + 1);
             stageRows(pos + 1, false);
           }
+          bool storesBehind = false; // the previous iteration's row stores were issued after this site's requests
           for (; pos >= lo; --pos) {
             const int q = pos + 1;
-            landed();
+            if (storesBehind) {
+              landedBeforeRowStores();
+            } else {
+              landed();
+            }
+            storesBehind = true;
             if (pos - 1 >= lo) {
               stageEmis(q - 1);
               stageRows(q - 1, false);
