@@ -196,10 +196,20 @@ bool halfAvailable(int mode, const fsmc_model* m)
   return mode == kModeIbd && !m->sequence && m->K == 69;
 }
 
-// The wide-model kernel (four lanes per pair, fsmc_kernels_q4.h): K = 256, array mode, IBD and dump consumers.
+// The wide-model kernel (four lanes per pair, fsmc_kernels_q4.h): 70 <= K <= 256, array mode, IBD and dump
+// consumers.  fsmc_model_create pads such a model's rows to KP = 128, 192 or 256 floats = 4 x the states per lane.
 bool quarterLanes(int mode, const fsmc_model* m)
 {
-  return m->K == kQ4K && !m->sequence && (mode == kModeIbd || mode == kModeDump);
+  return m->K > 69 && m->K <= 4 * kQ4MaxStates && !m->sequence && (mode == kModeIbd || mode == kModeDump) &&
+         (m->KP == 128 || m->KP == 192 || m->KP == 256);
+}
+
+template <int KQ> KernelFn pickQuarterKernel(int mode, bool track)
+{
+  if (mode == kModeIbd) {
+    return track ? decode_kernel_q4<KQ, kModeIbd, true> : decode_kernel_q4<KQ, kModeIbd, false>;
+  }
+  return decode_kernel_q4<KQ, kModeDump, false>;
 }
 
 KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
@@ -207,9 +217,9 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
   if (quarterLanes(mode, m)) {
     if (mode == kModeIbd) {
       m->ctx->lastStride = 1;
-      return track ? decode_kernel_q4<kModeIbd, true> : decode_kernel_q4<kModeIbd, false>;
     }
-    return decode_kernel_q4<kModeDump, false>;
+    return m->KP == 128 ? pickQuarterKernel<32>(mode, track)
+                        : m->KP == 192 ? pickQuarterKernel<48>(mode, track) : pickQuarterKernel<64>(mode, track);
   }
   const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1;
   if (mode == kModeIbd) {
@@ -247,7 +257,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     const size_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
     L = std::max<size_t>(L, aEnd - g.from);
   }
-  const size_t K4 = q4 ? (size_t)kQ4F4 : (size_t)(m->K + 3) / 4;
+  const size_t K4 = q4 ? (size_t)m->KP / 16 : (size_t)(m->K + 3) / 4; // q4: a lane stores KP/4 states
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes);
   size_t C, maxChunks;
@@ -549,6 +559,10 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   m->ctx = ctx;
   m->K = d->K;
   m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
+  if (d->K > 69) {
+    // wide models: four lanes per pair hold KP/4 states each (fsmc_kernels_q4.h); the padding states are ghosts
+    m->KP = d->K <= 128 ? 128 : d->K <= 192 ? 192 : 256;
+  }
   m->S = d->S;
   m->nRows = d->n_rows;
   m->stateThr = d->state_threshold;

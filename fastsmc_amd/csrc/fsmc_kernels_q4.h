@@ -1,8 +1,9 @@
-// fsmc_kernels_q4.h -- the decode kernel for wide models (K = 256, BASELINE.json config 4).
+// fsmc_kernels_q4.h -- the decode kernel for wide models (70 <= K <= 256; K = 256 is BASELINE.json config 4).
 //
 // Three 256-float K-vectors per pair do not fit a lane's 256 registers, and the runtime-K kernel that keeps them in
-// scratch memory is latency-bound (1.7 % of the HBM roofline).  Here FOUR adjacent lanes share a pair: lane 4p+q
-// holds states [64q, 64q+64) of pair p in registers, a wavefront decodes 16 pairs.
+// scratch memory is latency-bound (1.7 % of the HBM roofline at K = 256).  Here FOUR adjacent lanes share a pair:
+// lane 4p+q holds states [KQ*q, KQ*q+KQ) of pair p in registers (KQ = 32, 48 or 64 states per lane), a wavefront
+// decodes 16 pairs.
 //   * every operation that is not part of a recurrence runs on all 64 lanes at once (each on its own 64 states);
 //   * the first-order recurrences (BU, BL, AU, suffix sum, scaling sums) are inherently sequential in k, hence
 //     sequential across the four lanes of a pair: they run in four PHASES, quarter after quarter, under the lane
@@ -13,6 +14,13 @@
 // Operands differ between the quarters of a wave, so they cannot be SGPRs: the four table rows and the three
 // emission rows of a site are landed in LDS by LDS-DMA one site ahead (no VGPR staging) and read per lane.
 // Beta stride 1, array mode, consumers: IBD scan (with segment ages) and the posterior dump.
+//
+// A model with K < 4*KQ states is padded with GHOST states K .. 4*KQ-1 whose table, emission and prior entries are
+// zero (the host pads every row to KP = 4*KQ floats).  Ghost values stay exactly +0 through every operation -- and a
+// sum that adds +0 in state order is the same sum -- with one exception: beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k] is
+// BL[k] for a ghost, so the backward step multiplies beta' by a 1/0 mask row before the scaling sum (x*1.0f is
+// exact).  The boundary cases of the real last state need no special code either: BU[K-1] = U*0 + RR*0 = 0 and the
+// forward term's B[K-1]*alphaC[K] = B*0 = 0 are what the reference writes explicitly (HMM.cpp:986-1005, 823-826).
 #pragma once
 
 #include "fsmc_kernels.h"
@@ -20,10 +28,7 @@
 namespace fsmc
 {
 
-constexpr int kQ4States = 64;             // states per lane
-constexpr int kQ4K = 4 * kQ4States;       // 256
-constexpr int kQ4F4 = kQ4States / 4;      // float4 per lane per K-vector
-constexpr int kQ4RowF4 = kQ4K / 4;        // float4 per table / emission row
+constexpr int kQ4MaxStates = 64;          // largest KQ: 4 * 64 = 256 states
 constexpr int kQuadUp = 0xF9;             // quad_perm [1,2,3,3]: lane q reads lane q+1
 constexpr int kQuadDn = 0x90;             // quad_perm [0,0,1,2]: lane q reads lane q-1
 constexpr int kQuadB3 = 0xFF;             // every lane of the quad reads lane 3
@@ -45,7 +50,7 @@ __device__ __forceinline__ float f4at(const float4& q, const int i)
 
 // Sum of a lane's 64 values continued across the four lanes of a pair in state order: returns the running sum after
 // this lane's states in every lane; `total` (all lanes) is the sum over the 256 states (HmmUtils.cpp:121-128 order).
-__device__ __forceinline__ float quadOrderedSum(const float (&v)[kQ4States], const int qd)
+template <int KQ> __device__ __forceinline__ float quadOrderedSum(const float (&v)[KQ], const int qd)
 {
   float sOut = 0.f;
 #pragma nounroll
@@ -54,7 +59,7 @@ __device__ __forceinline__ float quadOrderedSum(const float (&v)[kQ4States], con
     if (qd == ph) {
       float s = (ph == 0) ? 0.f : c;
 #pragma unroll
-      for (int j = 0; j < kQ4States; ++j) {
+      for (int j = 0; j < KQ; ++j) {
         s = s + v[j];
       }
       sOut = s;
@@ -65,13 +70,14 @@ __device__ __forceinline__ float quadOrderedSum(const float (&v)[kQ4States], con
 
 // One backward step.  b: beta of site pos+1 on entry, of site pos on exit.  w, x: scratch.  e: this lane's 16
 // emission float4 of site pos+1; rD/rB/rUsh/rRR: this lane's slices of the step's table rows (LDS).
-__device__ __forceinline__ void beta_step_q4(float (&b)[kQ4States], float (&w)[kQ4States], float (&x)[kQ4States],
-                                             const float4* e, const float4* rD, const float4* rB, const float4* rUsh,
-                                             const float4* rRR, const int qd)
+template <int KQ>
+__device__ __forceinline__ void beta_step_q4(float (&b)[KQ], float (&w)[KQ], float (&x)[KQ], const float4* e,
+                                             const float4* rD, const float4* rB, const float4* rUsh,
+                                             const float4* rRR, const float4* mask, const int qd)
 {
   // vec[k] = beta[k]*e[k] (kept in b), T[k] = U[k-1]*vec[k] (in x)
 #pragma unroll
-  for (int j4 = 0; j4 < kQ4F4; ++j4) {
+  for (int j4 = 0; j4 < (KQ / 4); ++j4) {
     const float4 em = e[j4];
     const float4 us = rUsh[j4];
     f32x2 v0 = {b[4 * j4], b[4 * j4 + 1]}, v1 = {b[4 * j4 + 2], b[4 * j4 + 3]};
@@ -96,10 +102,10 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[kQ4States], float (&w)[k
       const float cT = quadMove<kQuadUp>(tLow);
       const float cB = quadMove<kQuadUp>(buLow);
       if (qd == ph) {
-        float4 rr = rRR[kQ4F4 - 1];
-        w[kQ4States - 1] = (ph == 3) ? 0.f : cT + rr.w * cB;
+        float4 rr = rRR[(KQ / 4) - 1];
+        w[KQ - 1] = (ph == 3) ? 0.f : cT + rr.w * cB;
 #pragma unroll
-        for (int j4 = kQ4F4 - 1; j4 >= 0; --j4) {
+        for (int j4 = (KQ / 4) - 1; j4 >= 0; --j4) {
           float4 nrr = rr;
           if (j4 > 0) {
             nrr = rRR[j4 - 1];
@@ -107,7 +113,7 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[kQ4States], float (&w)[k
 #pragma unroll
           for (int i = 3; i >= 0; --i) {
             const int j = 4 * j4 + i;
-            if (j < kQ4States - 1) {
+            if (j < KQ - 1) {
               w[j] = x[j + 1] + f4at(rr, i) * w[j + 1];
             }
           }
@@ -120,7 +126,7 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[kQ4States], float (&w)[k
   }
   // bv = B*vec (in x), then BL as running sums: x[j] = BL of state j+1 (HMM.cpp:1008-1016)
 #pragma unroll
-  for (int j4 = 0; j4 < kQ4F4; ++j4) {
+  for (int j4 = 0; j4 < (KQ / 4); ++j4) {
     const float4 bt = rB[j4];
     const f32x2 v0 = {b[4 * j4], b[4 * j4 + 1]}, v1 = {b[4 * j4 + 2], b[4 * j4 + 3]};
     const f32x2 c0 = {bt.x, bt.y}, c1 = {bt.z, bt.w};
@@ -140,16 +146,16 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[kQ4States], float (&w)[k
         blIn = (ph == 0) ? 0.f : c;
         x[0] = blIn + x[0];
 #pragma unroll
-        for (int j = 1; j < kQ4States; ++j) {
+        for (int j = 1; j < KQ; ++j) {
           x[j] = x[j - 1] + x[j];
         }
-        blOut = x[kQ4States - 1];
+        blOut = x[KQ - 1];
       }
     }
   }
   // beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k]
 #pragma unroll
-  for (int j4 = 0; j4 < kQ4F4; ++j4) {
+  for (int j4 = 0; j4 < (KQ / 4); ++j4) {
     const float4 d = rD[j4];
     const f32x2 v0 = {b[4 * j4], b[4 * j4 + 1]}, v1 = {b[4 * j4 + 2], b[4 * j4 + 3]};
     const f32x2 d0 = {d.x, d.y}, d1 = {d.z, d.w};
@@ -160,23 +166,29 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[kQ4States], float (&w)[k
     b[4 * j4 + 3] = p1.y;
   }
 #pragma unroll
-  for (int j = 0; j < kQ4States; ++j) {
+  for (int j = 0; j < KQ; ++j) {
     const float bl = (j == 0) ? blIn : x[j - 1];
     b[j] = bl + b[j];
   }
 #pragma unroll
-  for (int j = 0; j < kQ4States; j += 2) {
-    const f32x2 t = {b[j], b[j + 1]};
-    const f32x2 bu = {w[j], w[j + 1]};
-    const f32x2 r = t + bu;
-    w[j] = r.x;
-    w[j + 1] = r.y;
+  for (int j4 = 0; j4 < (KQ / 4); ++j4) {
+    const float4 m = mask[j4]; // 1 for a state of the model, 0 for a ghost
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 4 * j4 + 2 * h;
+      const f32x2 t = {b[j], b[j + 1]};
+      const f32x2 bu = {w[j], w[j + 1]};
+      const f32x2 mm = {f4at(m, 2 * h), f4at(m, 2 * h + 1)};
+      const f32x2 r = (t + bu) * mm;
+      w[j] = r.x;
+      w[j + 1] = r.y;
+    }
   }
   const float total = quadOrderedSum(w, qd);
   const float c = 1.0f / total;
   const f32x2 cc = {c, c};
 #pragma unroll
-  for (int j = 0; j < kQ4States; j += 2) {
+  for (int j = 0; j < KQ; j += 2) {
     const f32x2 t = {w[j], w[j + 1]};
     const f32x2 r = t * cc;
     b[j] = r.x;
@@ -185,9 +197,10 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[kQ4States], float (&w)[k
 }
 
 // One forward step (HMM.cpp:799-830) + scaling.  a: alpha of site pos-1 on entry, of site pos on exit.
-__device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[kQ4States], float (&x)[kQ4States],
-                                              const float4* e, const float4* rD, const float4* rB, const float4* rU,
-                                              const float4* rC, const int qd)
+template <int KQ>
+__device__ __forceinline__ void alpha_step_q4(float (&a)[KQ], float (&w)[KQ], float (&x)[KQ], const float4* e,
+                                              const float4* rD, const float4* rB, const float4* rU, const float4* rC,
+                                              const int qd)
 {
   // suffix sums one slot down: w[j] = alphaC of the state after j (quarter 3 first)
   {
@@ -197,14 +210,14 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[
       const float c = quadMove<kQuadUp>(cOut);
       if (qd == ph) {
         if (ph == 3) {
-          w[kQ4States - 1] = 0.f; // no state after the last one (never used)
-          w[kQ4States - 2] = a[kQ4States - 1];
+          w[KQ - 1] = 0.f; // no state after the last one (never used)
+          w[KQ - 2] = a[KQ - 1];
         } else {
-          w[kQ4States - 1] = c;
-          w[kQ4States - 2] = w[kQ4States - 1] + a[kQ4States - 1];
+          w[KQ - 1] = c;
+          w[KQ - 2] = w[KQ - 1] + a[KQ - 1];
         }
 #pragma unroll
-        for (int j = kQ4States - 2; j >= 1; --j) {
+        for (int j = KQ - 2; j >= 1; --j) {
           w[j - 1] = w[j] + a[j];
         }
         cOut = w[0] + a[0];
@@ -213,7 +226,7 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[
   }
   // ua = U*alpha (in x), then AU as a running recurrence: x[j] = AU of state j+1
 #pragma unroll
-  for (int j4 = 0; j4 < kQ4F4; ++j4) {
+  for (int j4 = 0; j4 < (KQ / 4); ++j4) {
     const float4 u = rU[j4];
     const f32x2 v0 = {a[4 * j4], a[4 * j4 + 1]}, v1 = {a[4 * j4 + 2], a[4 * j4 + 3]};
     const f32x2 u0 = {u.x, u.y}, u1 = {u.z, u.w};
@@ -234,9 +247,9 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[
         float au = auIn;
         float4 cr = rC[0];
 #pragma unroll
-        for (int j4 = 0; j4 < kQ4F4; ++j4) {
+        for (int j4 = 0; j4 < (KQ / 4); ++j4) {
           float4 ncr = cr;
-          if (j4 + 1 < kQ4F4) {
+          if (j4 + 1 < (KQ / 4)) {
             ncr = rC[j4 + 1];
           }
 #pragma unroll
@@ -253,7 +266,7 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[
   }
   // term = AU + D*alpha (+ B*alphaC of the next state), alpha' = e * term
 #pragma unroll
-  for (int j4 = 0; j4 < kQ4F4; ++j4) {
+  for (int j4 = 0; j4 < (KQ / 4); ++j4) {
     const float4 d = rD[j4];
     const float4 bt = rB[j4];
     const float4 em = e[j4];
@@ -270,11 +283,8 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[
       f32x2 t;
       t.x = ((j == 0) ? auIn : x[j - 1]) + da.x;
       t.y = x[j] + da.y;
-      f32x2 t2 = t + bw;
-      if (j + 1 == kQ4States - 1) {
-        // the model's last state has no B term (HMM.cpp:823-826): only in the top quarter
-        t2.y = (qd == 3) ? t.y : t2.y;
-      }
+      // (the model's last state has no B term, HMM.cpp:823-826: its alphaC slot is 0, and term + B*0 is term)
+      const f32x2 t2 = t + bw;
       const f32x2 o = ee * t2;
       w[j] = o.x;
       w[j + 1] = o.y;
@@ -284,7 +294,7 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[
   const float c = 1.0f / total;
   const f32x2 cc = {c, c};
 #pragma unroll
-  for (int j = 0; j < kQ4States; j += 2) {
+  for (int j = 0; j < KQ; j += 2) {
     const f32x2 t = {w[j], w[j + 1]};
     const f32x2 r = t * cc;
     a[j] = r.x;
@@ -294,27 +304,29 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[kQ4States], float (&w)[
 
 // Segment ages from the per-state sums of the four lanes of a pair (columns lane0 .. lane0+3 of the wave's plane),
 // walked in state order by the pair's first lane (HMM.cpp:1087-1107).
-__device__ __forceinline__ float spsAtQ4(const float4* col0, const int k)
+template <int KQ> __device__ __forceinline__ float spsAtQ4(const float4* col0, const int k)
 {
-  const int qq = k >> 6, j = k & 63;
+  const int qq = k / KQ, j = k - qq * KQ;
   return reinterpret_cast<const float*>(col0 + (size_t)(j >> 2) * kWave + qq)[j & 3];
 }
-__device__ __forceinline__ void segment_ages_q4(const unsigned nAge, const float4* col0, cfloat_p pi, cfloat_p expT,
-                                                const bool wantMean, const bool wantMap, float& mean, float& mapv)
+template <int KQ>
+__device__ __forceinline__ void segment_ages_q4(const int K, const unsigned nAge, const float4* col0, cfloat_p pi,
+                                                cfloat_p expT, const bool wantMean, const bool wantMap, float& mean,
+                                                float& mapv)
 {
   mean = 0.f;
   mapv = 0.f;
-  const int n = (unsigned)kQ4K < nAge ? kQ4K : (int)nAge;
+  const int n = (unsigned)K < nAge ? K : (int)nAge;
   if (wantMean) {
     float acc = 0.f;
 #pragma nounroll
     for (int k = 0; k < n; ++k) {
-      acc = acc + spsAtQ4(col0, k);
+      acc = acc + spsAtQ4<KQ>(col0, k);
     }
     const float norm = 1.f / acc;
 #pragma nounroll
     for (int k = 0; k < n; ++k) {
-      mean = mean + (norm * spsAtQ4(col0, k)) * expT[k];
+      mean = mean + (norm * spsAtQ4<KQ>(col0, k)) * expT[k];
     }
   }
   if (wantMap) {
@@ -322,7 +334,7 @@ __device__ __forceinline__ void segment_ages_q4(const unsigned nAge, const float
     float bestT = 0.f;
 #pragma nounroll
     for (int k = 0; k < n; ++k) {
-      const float r = spsAtQ4(col0, k) / pi[k];
+      const float r = spsAtQ4<KQ>(col0, k) / pi[k];
       if (k == 0 || best < r) {
         best = r;
         bestT = expT[k];
@@ -333,20 +345,31 @@ __device__ __forceinline__ void segment_ages_q4(const unsigned nAge, const float
 }
 
 // Work item = a quarter of a group: pairs [16*sub, 16*sub+16) of group g; item index = 4*g + sub.
-template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void decode_kernel_q4(const KParams p)
+template <int KQ, int MODE, bool TRACK>
+__global__ __launch_bounds__(kWave, 2) void decode_kernel_q4(const KParams p)
 {
   static_assert(MODE == kModeIbd || MODE == kModeDump, "the wide-model kernel has the IBD and the dump consumer");
-  constexpr int KQ = kQ4States;
-  __shared__ float4 betaLds[kQ4F4 * kWave];      // landing zone of the next site's beta row (LDS-DMA), 16 KiB
-  __shared__ float4 emisLds[2][3 * kQ4RowF4];    // two sites x three observation classes, 6 KiB
-  __shared__ float4 rowLds[2][4 * kQ4RowF4];     // two sites x four table rows, 8 KiB
+  static_assert(KQ % 4 == 0 && KQ <= kQ4MaxStates, "states per lane");
+  __shared__ float4 betaLds[(KQ / 4) * kWave]; // landing zone of the next site's beta row (LDS-DMA), 16 KiB at KQ = 64
+  __shared__ float4 emisLds[2][3 * KQ];        // two sites x three observation classes (KQ float4 = 4*KQ states a row)
+  __shared__ float4 rowLds[2][4 * KQ];         // two sites x four table rows
+  __shared__ float4 maskLds[KQ];               // 1.0f for the model's states, 0.0f for the ghosts
+  const int K = p.K;                           // states of the model, <= 4*KQ = p.KP
 
   const int lane = threadIdx.x;
   const int qd = lane & 3; // which quarter of the states
   const int pp = lane >> 2; // which pair of the sub-group
+  if (lane < KQ) {
+    maskLds[lane] = make_float4(4 * lane < K ? 1.f : 0.f, 4 * lane + 1 < K ? 1.f : 0.f, 4 * lane + 2 < K ? 1.f : 0.f,
+                                4 * lane + 3 < K ? 1.f : 0.f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const float4* const maskOf = &maskLds[(KQ / 4) * qd];
   const cfloat_p tPi = (cfloat_p)p.pi, tExpT = (cfloat_p)p.expT;
   const cint_p tStepRow = (cint_p)p.stepRow;
-  const size_t vecF4 = (size_t)kQ4F4 * kWave;
+  const size_t vecF4 = (size_t)(KQ / 4) * kWave;
   float4* const chunkbuf = p.ws + (size_t)blockIdx.x * p.wsSlot;
   float4* const ckpt = chunkbuf + (size_t)p.chunk * vecF4;
   float4* const saveA = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
@@ -360,27 +383,34 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
   // LDS-DMA of one site's rows into ring slot (site & 1): asynchronous, no VGPRs.  A slot is only rewritten after
   // every LDS read of the step that used it has returned (s_waitcnt lgkmcnt(0) before the request).
   auto stageEmis = [&](const int site) {
-    const float4* src = p.emis3 + (size_t)site * (3 * kQ4RowF4) + lane;
+    const float4* src = p.emis3 + (size_t)site * (3 * KQ);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < (3 * KQ + kWave - 1) / kWave; ++i) {
+      if (i * kWave + lane < 3 * KQ) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      __builtin_amdgcn_global_load_lds(src + i * kWave, &emisLds[site & 1][i * kWave], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + i * kWave + lane, &emisLds[site & 1][i * kWave], 16, 0, 0);
 #endif
+      }
     }
   };
+  // rows of the step into / out of `site`: D, B and (forward) U, columnRatios or (backward) Ush, RR -- 4*KQ float4
+  // in LDS order; lane idx fetches float4 idx % KQ of row idx / KQ
   auto stageRows = [&](const int site, const bool forward) {
-    const float4* rs = rowSets4 + (size_t)tStepRow[site] * (kRowSetParts * kQ4RowF4) + lane;
+    const float4* rs = rowSets4 + (size_t)tStepRow[site] * (kRowSetParts * KQ);
+    const float4* r2 = forward ? rs + kRowU * KQ : rs + kRowUsh * KQ;
+    const float4* r3 = forward ? cR4 : rs + kRowRR * KQ;
+#pragma unroll
+    for (int i = 0; i < (4 * KQ + kWave - 1) / kWave; ++i) {
+      const int idx = i * kWave + lane;
+      if (idx < 4 * KQ) {
+        const int r = idx / KQ;
+        const int off = idx - r * KQ;
+        const float4* src = (r == 0 ? rs + kRowD * KQ : r == 1 ? rs + kRowB * KQ : r == 2 ? r2 : r3) + off;
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(rs + kRowD * kQ4RowF4, &rowLds[site & 1][0 * kQ4RowF4], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(rs + kRowB * kQ4RowF4, &rowLds[site & 1][1 * kQ4RowF4], 16, 0, 0);
-    if (forward) {
-      __builtin_amdgcn_global_load_lds(rs + kRowU * kQ4RowF4, &rowLds[site & 1][2 * kQ4RowF4], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(cR4 + lane, &rowLds[site & 1][3 * kQ4RowF4], 16, 0, 0);
-    } else {
-      __builtin_amdgcn_global_load_lds(rs + kRowUsh * kQ4RowF4, &rowLds[site & 1][2 * kQ4RowF4], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(rs + kRowRR * kQ4RowF4, &rowLds[site & 1][3 * kQ4RowF4], 16, 0, 0);
-    }
+        __builtin_amdgcn_global_load_lds(src, &rowLds[site & 1][i * kWave], 16, 0, 0);
 #endif
+      }
+    }
   };
   auto landed = [&]() { // every outstanding DMA (and store) of this wave is done and visible to its LDS reads
     FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
@@ -398,7 +428,7 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
   };
   auto fetchBeta = [&](const float4* src) {
 #pragma unroll
-    for (int k4 = 0; k4 < kQ4F4; ++k4) {
+    for (int k4 = 0; k4 < (KQ / 4); ++k4) {
 #if defined(__HIP_DEVICE_COMPILE__)
       __builtin_amdgcn_global_load_lds(src + (size_t)k4 * kWave, &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
 #endif
@@ -455,10 +485,10 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
     };
     // this lane's slices of a staged site
     auto emisOf = [&](const int site, const int cls) -> const float4* {
-      return &emisLds[site & 1][cls * kQ4RowF4 + kQ4F4 * qd];
+      return &emisLds[site & 1][cls * KQ + (KQ / 4) * qd];
     };
     auto rowOf = [&](const int site, const int t) -> const float4* {
-      return &rowLds[site & 1][t * kQ4RowF4 + kQ4F4 * qd];
+      return &rowLds[site & 1][t * KQ + (KQ / 4) * qd];
     };
 
     float w[KQ], x[KQ];
@@ -466,14 +496,18 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
     // one backward step out of site q (rows of q must be staged): beta(q) -> beta(q-1)
     auto betaStep = [&](float (&b)[KQ], const int q) {
       const int c = obsClass(q);
-      beta_step_q4(b, w, x, emisOf(q, c), rowOf(q, 0), rowOf(q, 1), rowOf(q, 2), rowOf(q, 3), qd);
+      beta_step_q4<KQ>(b, w, x, emisOf(q, c), rowOf(q, 0), rowOf(q, 1), rowOf(q, 2), rowOf(q, 3), maskOf, qd);
     };
     auto betaInit = [&](float (&b)[KQ]) {
-      // all ones, scaled: the sum of K ones is exact (HMM.cpp:887-897)
-      const float c = 1.0f / (float)kQ4K;
+      // all ones, scaled: the sum of K ones is exact (HMM.cpp:887-897); ghosts are zero
+      const float c = 1.0f / (float)K;
 #pragma unroll
-      for (int j = 0; j < KQ; ++j) {
-        b[j] = 1.0f * c;
+      for (int j4 = 0; j4 < (KQ / 4); ++j4) {
+        const float4 m = maskOf[j4];
+        b[4 * j4] = m.x * c;
+        b[4 * j4 + 1] = m.y * c;
+        b[4 * j4 + 2] = m.z * c;
+        b[4 * j4 + 3] = m.w * c;
       }
     };
 
@@ -523,8 +557,8 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
       const unsigned idx = atomicAdd(&p.counters[1], 1u);
       float mean = 0.f, mapv = 0.f;
       if constexpr (TRACK) {
-        segment_ages_q4(p.ageThr, spsMem, tPi, tExpT, (p.flags & FSMC_WANT_MEAN) != 0, (p.flags & FSMC_WANT_MAP) != 0,
-                        mean, mapv);
+        segment_ages_q4<KQ>(K, p.ageThr, spsMem, tPi, tExpT, (p.flags & FSMC_WANT_MEAN) != 0,
+                            (p.flags & FSMC_WANT_MAP) != 0, mean, mapv);
       }
       if (idx < p.recCap) {
         fsmc_ibd_record r;
@@ -600,8 +634,8 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
         if (pos == from) {
           // alpha at the first site: pi * emission, scaled (HMM.cpp:736-747)
 #pragma unroll
-          for (int j4 = 0; j4 < kQ4F4; ++j4) {
-            const float4 pv = pi4[kQ4F4 * qd + j4];
+          for (int j4 = 0; j4 < (KQ / 4); ++j4) {
+            const float4 pv = pi4[(KQ / 4) * qd + j4];
             const float4 em = e[j4];
             w[4 * j4] = pv.x * em.x;
             w[4 * j4 + 1] = pv.y * em.y;
@@ -615,11 +649,11 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
             a[j] = w[j] * c0;
           }
         } else {
-          alpha_step_q4(a, w, x, e, rowOf(pos, 0), rowOf(pos, 1), rowOf(pos, 2), rowOf(pos, 3), qd);
+          alpha_step_q4<KQ>(a, w, x, e, rowOf(pos, 0), rowOf(pos, 1), rowOf(pos, 2), rowOf(pos, 3), qd);
         }
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
 #pragma unroll
-        for (int j4 = 0; j4 < kQ4F4; ++j4) {
+        for (int j4 = 0; j4 < (KQ / 4); ++j4) {
           const float4 bv = betaLds[j4 * kWave + lane];
           w[4 * j4] = a[4 * j4] * bv.x;
           w[4 * j4 + 1] = a[4 * j4 + 1] * bv.y;
@@ -637,12 +671,14 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
         }
 
         if (MODE == kModeDump) {
-          float* out = p.dumpOut + p.dumpOffsets[g] + (size_t)(pos - from) * kQ4K * kWave + (size_t)(KQ * qd) * kWave +
+          float* out = p.dumpOut + p.dumpOffsets[g] + (size_t)(pos - from) * K * kWave + (size_t)(KQ * qd) * kWave +
                        pairInGroup;
           if (valid) {
 #pragma unroll
             for (int j = 0; j < KQ; ++j) {
-              out[(size_t)j * kWave] = w[j] * cq;
+              if (KQ * qd + j < K) {
+                out[(size_t)j * kWave] = w[j] * cq;
+              }
             }
           }
         }
@@ -659,7 +695,7 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
                 if (qd == ph) {
                   float s = (ph == 0) ? 0.f : cIn;
 #pragma unroll
-                  for (int j4 = 0; j4 < kQ4F4; ++j4) {
+                  for (int j4 = 0; j4 < (KQ / 4); ++j4) {
                     if ((unsigned)(KQ * ph + 4 * j4) < p.stateThr) {
 #pragma unroll
                       for (int i = 0; i < 4; ++i) {
@@ -687,7 +723,7 @@ template <int MODE, bool TRACK> __global__ __launch_bounds__(kWave, 2) void deco
             if constexpr (TRACK) {
               if (level != 4) {
 #pragma unroll
-                for (int j4 = 0; j4 < kQ4F4; ++j4) {
+                for (int j4 = 0; j4 < (KQ / 4); ++j4) {
                   if ((unsigned)(KQ * qd + 4 * j4) < p.ageThr) {
                     float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (!opening) {

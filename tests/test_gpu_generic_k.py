@@ -1,5 +1,6 @@
-"""The runtime-K kernel instantiation (any K <= 256; K = 69 has its own unrolled instantiation) against the
-oracle: config-4-style wide models and small ones, all output modes."""
+"""Models other than K = 69 against the oracle, all output modes: the runtime-K kernel instantiation (K < 69, and the
+per-pair / sum consumers of any K) and the wide-model kernel (70 <= K <= 256: four lanes per pair, 32 / 48 / 64 states
+per lane, padded with ghost states -- K = 70, 100, 128 exactly, 130, 192 exactly, 200, 256 exactly)."""
 import numpy as np
 import pytest
 
@@ -19,7 +20,7 @@ def _problem(K, n_hap=64, S=200, seed=11):
     return pm, bits, folded
 
 
-@pytest.mark.parametrize("K", [5, 16, 70, 256])
+@pytest.mark.parametrize("K", [5, 16, 70, 100, 128, 130, 192, 200, 256])
 def test_generic_kernel_matches_oracle(K):
     pm, bits, folded = _problem(K)
     pairs = O.enumerate_all_pairs(32)[:96]

@@ -80,8 +80,8 @@ def c1():
     ctx.close()
 
 
-def k256():
-    pm, bits, _, _ = prepared(600, 3000, 256)  # 179 700 pairs = 2808 groups: every resident wave has work
+def k256(K=256):
+    pm, bits, _, _ = prepared(600, 3000, K)  # 179 700 pairs = 2808 groups: every resident wave has work
     pairs = all_pairs(300)
     ctx = capi.Context(0)
     model = ctx.create_model(pm)
@@ -89,7 +89,7 @@ def k256():
     pr = pairs.view(capi.PAIR_DTYPE).reshape(-1)
     ctx.upload_worklist(pr, capi.whole_sequence_groups(len(pr), pm.S, batch=64))
     dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1], reps=1)
-    print(json.dumps({"config": "k256_ibd", "pairs": len(pr), "sites": pm.S, "K": pm.K, "seconds": dt,
+    print(json.dumps({"config": f"k{K}_ibd", "pairs": len(pr), "sites": pm.S, "K": pm.K, "seconds": dt,
                       "pairs_per_s": len(pr) / dt, "pair_sites_per_s": len(pr) * pm.S / dt, "kernel_ms": ctx.last_kernel_ms(),
                       "algorithmic_GBps": len(pr) * pm.S * (8 * pm.K + 0.25) / dt / 1e9, "records": int(rec.size)}))
     ctx.close()
@@ -147,4 +147,4 @@ def hashing():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
-        {"c1": c1, "k256": k256, "hashing": hashing}[w]()
+        {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "hashing": hashing}[w]()
