@@ -230,6 +230,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
 
 struct LaunchPlan {
   int chunk = 0;
+  int chunkRows = 0; // rows of the chunk buffer (chunk, or half of it with beta stride 2)
   int maxChunks = 0;
   size_t wsSlot = 0; // float4 per slot
   int slots = 0;
@@ -260,21 +261,36 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   const size_t K4 = q4 ? (size_t)m->KP / 16 : (size_t)(m->K + 3) / 4; // q4: a lane stores KP/4 states
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes);
+  // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
+  const bool half = halfAvailable(mode, m) && ctx->betaStride != 1;
+  auto chunkRows = [&](size_t c) { return half ? (c + 1) / 2 : c; };
+  const size_t rowsAvail = (size_t)(limit / (vecBytes * slots)); // rows one resident wave may hold
   size_t C, maxChunks;
-  if ((L + 5) * vecBytes * slots <= limit) {
+  if (chunkRows(L) + 5 <= rowsAvail) {
     C = L;
     maxChunks = 1;
   } else {
-    C = ctx->chunkSites ? (size_t)ctx->chunkSites : (size_t)std::ceil(std::sqrt((double)L));
+    // A window no longer than a chunk skips the rebuild pass (single-chunk layout), and chunk length costs nothing
+    // else, so the default is generous: 2048 sites (the hashing pre-filter's windows are a few hundred) or
+    // sqrt(window) if that is larger, shrunk to what the workspace limit allows.
+    C = ctx->chunkSites ? (size_t)ctx->chunkSites
+                        : std::max<size_t>((size_t)std::ceil(std::sqrt((double)L)), 2048);
     C = std::min((C + 15) / 16 * 16, (L + 15) / 16 * 16);
+    auto fits = [&](size_t c) { return chunkRows(c) + (L + c - 1) / c + 5 <= rowsAvail; };
+    if (!ctx->chunkSites) {
+      while (C > 16 && !fits(C)) {
+        C = std::max<size_t>(16, (C / 2 + 15) / 16 * 16);
+      }
+    }
     maxChunks = (L + C - 1) / C;
-    if ((C + maxChunks + 5) * vecBytes * slots > limit) {
+    if (!fits(C)) {
       return fail(ctx, FSMC_ENOMEM, "workspace limit too small for the decode window");
     }
   }
   plan.chunk = (int)C;
+  plan.chunkRows = (int)chunkRows(C);
   plan.maxChunks = (int)maxChunks;
-  plan.wsSlot = (C + maxChunks + 2 + 2) * K4 * kWave;
+  plan.wsSlot = (chunkRows(C) + maxChunks + 2 + 2) * K4 * kWave;
   plan.slots = (int)slots;
   ctx->lastChunk = plan.chunk;
   ctx->lastMaxChunks = plan.maxChunks;
@@ -324,6 +340,7 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.W = (int)ctx->W;
   p.nGroups = (int)ctx->nGroups;
   p.chunk = plan.chunk;
+  p.chunkRows = plan.chunkRows;
   p.maxChunks = plan.maxChunks;
   p.flags = flags;
   p.pi = m->pi;

@@ -48,6 +48,7 @@ struct KParams {
   int W;       // 64-bit words per haplotype row
   int nGroups;
   int chunk;   // sites per chunk (C)
+  int chunkRows; // rows of the chunk buffer: C, or (C+1)/2 with beta stride 2
   int maxChunks;
   unsigned flags;
   const float* pi;    // [KP]
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
                tRowGapB = (cint_p)p.rowGapB;
   const size_t vecF4 = (size_t)K4 * kWave; // float4 per stored K-vector of a wave
   float4* const chunkbuf = p.ws + (size_t)blockIdx.x * p.wsSlot;
-  float4* const ckpt = chunkbuf + (size_t)p.chunk * vecF4;
+  float4* const ckpt = chunkbuf + (size_t)p.chunkRows * vecF4;
   float4* const saveA = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
   float4* const saveS = saveA + vecF4;
   const int C = p.chunk;

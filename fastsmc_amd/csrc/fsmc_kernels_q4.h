@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel_q4(const KParams p)
   const cint_p tStepRow = (cint_p)p.stepRow;
   const size_t vecF4 = (size_t)(KQ / 4) * kWave;
   float4* const chunkbuf = p.ws + (size_t)blockIdx.x * p.wsSlot;
-  float4* const ckpt = chunkbuf + (size_t)p.chunk * vecF4;
+  float4* const ckpt = chunkbuf + (size_t)p.chunkRows * vecF4;
   float4* const saveA = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
   float4* const saveS = saveA + vecF4;
   float4* const spsMem = saveS + lane;

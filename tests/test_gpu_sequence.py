@@ -101,7 +101,8 @@ def test_scan_window_and_chunked_stream(seq_problem):
         ctx.close()
         _assert_records_equal(got, want)
         np.testing.assert_array_equal(post[1][:, :, :36], _oracle_posterior(seq_problem, pm, pairs[64:], 0, pm.S))
-    assert plans[0] >= pm.S - 13 and plans[1] < 100 and plans[2] == 16
+    # whole window in one chunk; the largest chunk the 6-MB workspace allows (the window is chunked); the forced 16
+    assert plans[0] >= pm.S - 13 and plans[1] < 200 and plans[2] == 16
 
 
 def test_per_pair_and_sums(gpu, seq_problem):

@@ -144,7 +144,39 @@ def hashing():
                       "all_pairs": n_hap * (n_hap - 1) // 2 + 0}))
 
 
+def short_windows():
+    """The hashing regime (C5): batches of 32 pairs, each with its own short decode window (384-site median, as the
+    C1 hashing run of SURVEY.md §0.9) -- pair-sites/s of the IBD decode alone."""
+    pm, bits, _, _ = prepared(1000, 50000, 69)
+    rng = np.random.default_rng(7)
+    n_groups = 60000
+    lens = rng.choice([320, 384, 384, 448, 640, 1024, 5504], size=n_groups, p=[0.2, 0.3, 0.2, 0.1, 0.1, 0.08, 0.02])
+    starts = rng.integers(0, pm.S - lens)
+    groups = np.zeros(n_groups, capi.GROUP_DTYPE)
+    groups["first_pair"] = np.arange(n_groups) * 32
+    groups["n_pairs"] = 32
+    groups["from"] = starts
+    groups["to"] = starts + lens
+    groups["scan_from"] = starts + 16
+    groups["scan_to"] = starts + lens - 16
+    a = rng.integers(0, 1000, size=n_groups * 32).astype(np.uint32)
+    b = (a + 1 + rng.integers(0, 998, size=a.size).astype(np.uint32)) % 1000
+    pr = np.stack([a, b], axis=1).astype(np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    ctx.upload_worklist(pr, groups)
+    dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1])
+    ps = float((lens.astype(np.int64) * 32).sum())
+    print(json.dumps({"config": "short_windows_ibd", "groups": n_groups, "pairs": int(pr.size), "pair_sites": ps,
+                      "seconds": dt, "kernel_ms": ctx.last_kernel_ms(), "pair_sites_per_s": ps / dt,
+                      "pairs_per_s": pr.size / dt, "algorithmic_GBps": ps * (8 * 69 + 0.25) / dt / 1e9,
+                      "records": int(rec.size), "plan": ctx.info()}))
+    ctx.close()
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
-        {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "hashing": hashing}[w]()
+        {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "hashing": hashing,
+         "short": short_windows}[w]()
