@@ -30,10 +30,10 @@ HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); ~6.3e12 is the meas
 
 def measured_traffic(n_hap: int, n_sites: int, K: int, beta_stride: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01b_traffic.json for beta stride 2, profiles/r01_traffic.json for stride 1: separate --pmc FETCH_SIZE /
+    (profiles/r01c_traffic.json for beta stride 2, profiles/r01_traffic.json for stride 1: separate --pmc FETCH_SIZE /
     WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction).  PMC collection cannot run inside the timed process, so the
     figure is the committed measurement; it is reported only for the workload and kernel it was measured on."""
-    name = {1: "r01_traffic.json", 2: "r01b_traffic.json"}.get(beta_stride)
+    name = {1: "r01_traffic.json", 2: "r01c_traffic.json"}.get(beta_stride)
     if (n_hap, n_sites, K) != (1000, 50000, 69) or name is None:
         return None
     path = os.path.join(ROOT, "profiles", name)
