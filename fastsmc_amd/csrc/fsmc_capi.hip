@@ -200,7 +200,8 @@ bool halfAvailable(int mode, const fsmc_model* m)
 // consumers.  fsmc_model_create pads such a model's rows to KP = 128, 192 or 256 floats = 4 x the states per lane.
 bool quarterLanes(int mode, const fsmc_model* m)
 {
-  return m->K > 69 && m->K <= 4 * kQ4MaxStates && !m->sequence && (mode == kModeIbd || mode == kModeDump) &&
+  return m->K > 69 && m->K <= 4 * kQ4MaxStates && !m->sequence &&
+         (mode == kModeIbd || mode == kModeDump || mode == kModePerPair) &&
          (m->KP == 128 || m->KP == 192 || m->KP == 256);
 }
 
@@ -208,6 +209,9 @@ template <int KQ> KernelFn pickQuarterKernel(int mode, bool track)
 {
   if (mode == kModeIbd) {
     return track ? decode_kernel_q4<KQ, kModeIbd, true> : decode_kernel_q4<KQ, kModeIbd, false>;
+  }
+  if (mode == kModePerPair) {
+    return decode_kernel_q4<KQ, kModePerPair, false>;
   }
   return decode_kernel_q4<KQ, kModeDump, false>;
 }

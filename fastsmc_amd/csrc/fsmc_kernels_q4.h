@@ -13,7 +13,7 @@
 // instruction serves 16 pairs instead of 64.
 // Operands differ between the quarters of a wave, so they cannot be SGPRs: the four table rows and the three
 // emission rows of a site are landed in LDS by LDS-DMA one site ahead (no VGPR staging) and read per lane.
-// Beta stride 1, array mode, consumers: IBD scan (with segment ages) and the posterior dump.
+// Beta stride 1, array mode, consumers: IBD scan (with segment ages), posterior dump, per-pair mean / MAP rows.
 //
 // A model with K < 4*KQ states is padded with GHOST states K .. 4*KQ-1 whose table, emission and prior entries are
 // zero (the host pads every row to KP = 4*KQ floats).  Ghost values stay exactly +0 through every operation -- and a
@@ -348,7 +348,8 @@ __device__ __forceinline__ void segment_ages_q4(const int K, const unsigned nAge
 template <int KQ, int MODE, bool TRACK>
 __global__ __launch_bounds__(kWave, 2) void decode_kernel_q4(const KParams p)
 {
-  static_assert(MODE == kModeIbd || MODE == kModeDump, "the wide-model kernel has the IBD and the dump consumer");
+  static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModePerPair,
+                "the wide-model kernel has the IBD, the dump and the per-pair consumer");
   static_assert(KQ % 4 == 0 && KQ <= kQ4MaxStates, "states per lane");
   __shared__ float4 betaLds[(KQ / 4) * kWave]; // landing zone of the next site's beta row (LDS-DMA), 16 KiB at KQ = 64
   __shared__ float4 emisLds[2][3 * KQ];        // two sites x three observation classes (KQ float4 = 4*KQ states a row)
@@ -680,6 +681,47 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel_q4(const KParams p)
                 out[(size_t)j * kWave] = w[j] * cq;
               }
             }
+          }
+        }
+
+        if (MODE == kModePerPair) {
+          // HMM::writePerPairOutput (HMM.cpp:1378-1409): mean = sum_k post*E[t_k] (k ascending from 0.f), MAP = first
+          // strictly larger posterior -- both walk the states in order, quarter after quarter
+          const float4* const coal4 = reinterpret_cast<const float4*>(p.expCoal) + (KQ / 4) * qd;
+          float mOut = 0.f, bOut = 0.f;
+          int aOut = 0;
+#pragma nounroll
+          for (int ph = 0; ph < 4; ++ph) {
+            const float cM = quadMove<kQuadDn>(mOut);
+            const float cB = quadMove<kQuadDn>(bOut);
+            const int cA = __float_as_int(quadMove<kQuadDn>(__int_as_float(aOut)));
+            if (qd == ph) {
+              float mean = (ph == 0) ? 0.f : cM;
+              float best = (ph == 0) ? 0.f : cB;
+              int arg = (ph == 0) ? 0 : cA;
+#pragma unroll
+              for (int j4 = 0; j4 < (KQ / 4); ++j4) {
+                const float4 tc = coal4[j4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float post = w[4 * j4 + i] * cq;
+                  mean = mean + post * f4at(tc, i);
+                  if (best < post) {
+                    arg = KQ * ph + 4 * j4 + i;
+                    best = post;
+                  }
+                }
+              }
+              mOut = mean;
+              bOut = best;
+              aOut = arg;
+            }
+          }
+          const float mean = quadMove<kQuadB3>(mOut);
+          const int arg = __float_as_int(quadMove<kQuadB3>(__int_as_float(aOut)));
+          if (valid && qd == 0) {
+            if (p.ppMean) p.ppMean[(size_t)pairIdx * p.S + pos] = mean;
+            if (p.ppMap) p.ppMap[(size_t)pairIdx * p.S + pos] = arg;
           }
         }
 
