@@ -28,6 +28,12 @@
 namespace fsmc
 {
 
+// Waves per SIMD the compiler must leave room for.  At 64 states per lane the three K-vectors plus operands need
+// ~400 registers: with the 256 of two waves per SIMD 150 of them spill to scratch memory; one wave per SIMD gets
+// 512 (the rest in AGPRs, no scratch) and measured 14 % faster -- the LDS ring allows only five waves per CU anyway.
+#ifndef FSMC_Q4_MINBLOCKS
+#define FSMC_Q4_MINBLOCKS(KQ) ((KQ) == 64 ? 1 : 2)
+#endif
 constexpr int kQ4MaxStates = 64;          // largest KQ: 4 * 64 = 256 states
 constexpr int kQuadUp = 0xF9;             // quad_perm [1,2,3,3]: lane q reads lane q+1
 constexpr int kQuadDn = 0x90;             // quad_perm [0,0,1,2]: lane q reads lane q-1
@@ -346,7 +352,7 @@ __device__ __forceinline__ void segment_ages_q4(const int K, const unsigned nAge
 
 // Work item = a quarter of a group: pairs [16*sub, 16*sub+16) of group g; item index = 4*g + sub.
 template <int KQ, int MODE, bool TRACK>
-__global__ __launch_bounds__(kWave, 2) void decode_kernel_q4(const KParams p)
+__global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4(const KParams p)
 {
   static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModePerPair,
                 "the wide-model kernel has the IBD, the dump and the per-pair consumer");

@@ -178,5 +178,5 @@ def short_windows():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
-        {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "hashing": hashing,
+        {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "hashing": hashing,
          "short": short_windows}[w]()
