@@ -102,28 +102,29 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[KQ], float (&w)[KQ], flo
   }
   // BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1], BU[K-1] = 0 (HMM.cpp:986-1005): quarter 3 first
   {
+    // this lane's RR values are the same in whichever phase it is active: read them once, ahead of the chain (inside
+    // the chain every LDS read would sit on the critical path of a single active quarter)
+    float4 rrv[KQ / 4];
+#pragma unroll
+    for (int j4 = 0; j4 < (KQ / 4); ++j4) {
+      rrv[j4] = rRR[j4];
+    }
     float tLow = 0.f, buLow = 0.f; // T and BU of this lane's lowest state, for the quarter below
 #pragma nounroll
     for (int ph = 3; ph >= 0; --ph) {
       const float cT = quadMove<kQuadUp>(tLow);
       const float cB = quadMove<kQuadUp>(buLow);
       if (qd == ph) {
-        float4 rr = rRR[(KQ / 4) - 1];
-        w[KQ - 1] = (ph == 3) ? 0.f : cT + rr.w * cB;
+        w[KQ - 1] = (ph == 3) ? 0.f : cT + rrv[(KQ / 4) - 1].w * cB;
 #pragma unroll
         for (int j4 = (KQ / 4) - 1; j4 >= 0; --j4) {
-          float4 nrr = rr;
-          if (j4 > 0) {
-            nrr = rRR[j4 - 1];
-          }
 #pragma unroll
           for (int i = 3; i >= 0; --i) {
             const int j = 4 * j4 + i;
             if (j < KQ - 1) {
-              w[j] = x[j + 1] + f4at(rr, i) * w[j + 1];
+              w[j] = x[j + 1] + f4at(rrv[j4], i) * w[j + 1];
             }
           }
-          rr = nrr;
         }
         tLow = x[0];
         buLow = w[0];
@@ -244,6 +245,11 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[KQ], float (&w)[KQ], fl
   }
   float auIn = 0.f; // AU of this lane's first state
   {
+    float4 crv[KQ / 4]; // this lane's columnRatios, read once ahead of the chain
+#pragma unroll
+    for (int j4 = 0; j4 < (KQ / 4); ++j4) {
+      crv[j4] = rC[j4];
+    }
     float auOut = 0.f;
 #pragma nounroll
     for (int ph = 0; ph < 4; ++ph) {
@@ -251,20 +257,14 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[KQ], float (&w)[KQ], fl
       if (qd == ph) {
         auIn = (ph == 0) ? 0.f : c;
         float au = auIn;
-        float4 cr = rC[0];
 #pragma unroll
         for (int j4 = 0; j4 < (KQ / 4); ++j4) {
-          float4 ncr = cr;
-          if (j4 + 1 < (KQ / 4)) {
-            ncr = rC[j4 + 1];
-          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int j = 4 * j4 + i;
-            au = x[j] + f4at(cr, i) * au;
+            au = x[j] + f4at(crv[j4], i) * au;
             x[j] = au;
           }
-          cr = ncr;
         }
         auOut = au;
       }
