@@ -3,10 +3,11 @@
 never as bench.py's `value`):
   c1_ibd / c1_sums   300 haplotypes x 6760 sites, K = 69, all 44 850 pairs: IBD consumer, and the sum-over-pairs
                      consumer of the reference's own published timing (time_regression.py: 51.97 s on one CPU thread)
-  k256               generic (runtime-K) kernel, K = 256, reduced C4 shape
+  k256 k192 k128 k100  wide models (four lanes per pair), reduced C4 shape: 600 haplotypes x 3000 sites, all pairs
   hashing            FastSMC.run() end to end with the hashing pre-filter on, C2-sized files (parse + identify + decode +
-                     write), the C5 regime of many short windows
-Prints one JSON object per measurement.  Usage: python tools/measure_configs.py [c1 k256 hashing]"""
+                     write)
+  short              the IBD decode alone on 60 000 hashing-style batches (32 pairs, 320-5504-site windows): the C5 regime
+Prints one JSON object per measurement.  Usage: python tools/measure_configs.py [c1 k256 k192 k128 k100 hashing short]"""
 from __future__ import annotations
 
 import copy
