@@ -138,11 +138,6 @@ constexpr bool kTouch = false;
 #else
 constexpr bool kTouch = true;
 #endif
-#if defined(FSMC_TOUCH_ALL)
-constexpr bool kTouchAll = true;
-#else
-constexpr bool kTouchAll = false;
-#endif
 struct Touched {
   float r[4];
 };
