@@ -195,3 +195,23 @@ def test_binary_output_round_trip(files, small_problem, tmp_path):
         assert float(b[10]) == pytest.approx(float(t[10]), rel=1e-6)
         n += 1
     assert n == len(text) and n > 100
+
+
+def test_fastsmc_run_wide_model_matches_oracle_text(small_problem, tmp_path):
+    """The same end-to-end run with a 100-state model: routed to the wide-model kernel (four lanes per pair, 28 ghost
+    states) through the ordinary host path -- files, Data, HMM, FastSMC.run(), text output."""
+    sp = dict(small_problem)
+    sp["tables"] = synth.make_model_tables(100)
+    root = str(tmp_path / "syn100")
+    synth.write_haps_files(root, sp["haps"])
+    used = np.unique(np.concatenate([[0.0], O.step_rows(sp["tables"].keys, sp["gen"])[1][1:]]))
+    t = copy.copy(sp["tables"])
+    sel = np.nonzero(np.isin(t.keys, used.astype(np.float32)))[0]
+    t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
+    synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
+    out = str(tmp_path / "res100")
+    api.FastSMC(_params(root, out)).run()
+    got = gzip.open(out + ".1.1.FastSMC.ibd.gz", "rt").read()
+    want, n_pairs = _oracle_text(sp, list(range(32)), 1, 1)
+    assert n_pairs == 2 * 32 * 32 - 32 and want.count("\n") > 50
+    assert got == want
