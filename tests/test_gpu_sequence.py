@@ -182,3 +182,24 @@ def test_asmc_api_in_sequence_mode(seq_problem, tmp_path):
     for i in range(len(a)):
         np.testing.assert_array_equal(res.per_pair_posteriors[i], wpost[i])
     np.testing.assert_array_equal(res.sum_of_posteriors, sum_post)
+
+
+def test_sequence_mode_with_a_wide_model(seq_problem):
+    """A 100-state model in sequence mode: rows padded to 128 floats (the wide-model padding) on the runtime-K kernel."""
+    sp = seq_problem
+    tables = synth.make_model_tables(100)
+    haps = sp["haps"]
+    _, derived, _ = synth.fold_and_pack(haps.alleles)
+    pm = O.prepare_model(tables, sp["gen"], haps.bp, derived, 64, time=200, decoding_sequence=True)
+    pairs = O.enumerate_all_pairs(32)[:90]
+    want = O.decode_pairs_ibd(pm, sp["folded"], pairs, batch_size=64)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(sp["bits"], pm.S)
+    got = ctx.decode_ibd(model, _pairs_array(pairs), capi.whole_sequence_groups(len(pairs), pm.S))
+    ctx.upload_worklist(_pairs_array(pairs[:64]), capi.whole_sequence_groups(64, pm.S))
+    post = ctx.decode_posteriors(model)[0]
+    ctx.close()
+    assert want.size > 5
+    _assert_records_equal(got, want)
+    np.testing.assert_array_equal(post, _oracle_posterior(sp, pm, pairs[:64], 0, pm.S))
