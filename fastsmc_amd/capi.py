@@ -214,8 +214,8 @@ class Context:
         return float(ms.value)
 
     def phase_cycles(self) -> np.ndarray:
-        out = np.zeros(8, np.uint64)
-        self._check(self._L.fsmc_phase_cycles(self._h, _p(out), 8))
+        out = np.zeros(32, np.uint64)
+        self._check(self._L.fsmc_phase_cycles(self._h, _p(out), 32))
         return out
 
     def decode_ibd(self, model: "Model", pairs, groups, flags: int = FSMC_WANT_MEAN | FSMC_WANT_MAP) -> np.ndarray:

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -75,6 +76,7 @@ struct fsmc_model {
   float *pi = nullptr, *cR = nullptr, *expT = nullptr;
   float *D = nullptr, *B = nullptr, *U = nullptr, *RR = nullptr;
   float* rowSets = nullptr; // [rows][5][KP]: D | B | U | Ush | RR per key, Ush[k] = U[k-1] (kernels' RowSet)
+  float* ghostMask = nullptr; // [KP]: 1.0f for the K real states, 0.0f for the padding states
   int* stepRow = nullptr;
   bool sequence = false;
   int *rowGapF = nullptr, *rowSiteB = nullptr, *rowGapB = nullptr; // sequence mode (stepRow = forward site step)
@@ -251,6 +253,12 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   if (blocksPerCU > 8) {
     blocksPerCU = 8;
   }
+  if (const char* cap = std::getenv("FSMC_DIAG_WAVES_PER_CU")) { // occupancy experiments only
+    const int v = std::atoi(cap);
+    if (v >= 1 && v < blocksPerCU) {
+      blocksPerCU = v;
+    }
+  }
   const bool q4 = quarterLanes(mode, m); // a wave takes a quarter of a group and holds 64 states per lane
   size_t slots = (size_t)ctx->nCU * blocksPerCU;
   slots = std::min(slots, q4 ? 4 * ctx->nGroups : ctx->nGroups);
@@ -355,6 +363,7 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.U = m->U;
   p.rowSets = m->rowSets;
   p.RR = m->RR;
+  p.ghostMask = m->ghostMask;
   p.stepRow = m->stepRow;
   p.rowGapF = m->rowGapF;
   p.rowSiteB = m->rowSiteB;
@@ -445,8 +454,8 @@ int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->dCounters, 4 * sizeof(unsigned));
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->dPhase, 8 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipMemset(ctx->dPhase, 0, 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->dPhase, 32 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(ctx->dPhase, 0, 32 * sizeof(unsigned long long));
   if (e != hipSuccess) {
     std::string msg = std::string("context set-up failed: ") + hipGetErrorString(e);
     fsmc_ctx_destroy(ctx);
@@ -624,6 +633,11 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
     }
     rc = upload(ctx, &m->rowSets, rs.data(), rs.size());
   }
+  if (rc == FSMC_OK) {
+    std::vector<float> mask((size_t)KP, 0.f);
+    std::fill(mask.begin(), mask.begin() + K, 1.0f);
+    rc = upload(ctx, &m->ghostMask, mask.data(), mask.size());
+  }
   m->sequence = seq;
   auto upRows = [&](int** dst, const int32_t* src) {
     if (rc == FSMC_OK) {
@@ -689,7 +703,7 @@ void fsmc_model_destroy(fsmc_model* m)
       m->ctx->ibdModel = nullptr;
     }
   }
-  float* ptrs[] = {m->pi, m->cR, m->expT, m->D, m->B, m->U, m->rowSets, m->RR, (float*)m->emis3};
+  float* ptrs[] = {m->pi, m->cR, m->expT, m->D, m->B, m->U, m->rowSets, m->ghostMask, m->RR, (float*)m->emis3};
   for (float* q : ptrs) {
     if (q) (void)hipFree(q);
   }
@@ -817,12 +831,12 @@ int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms)
 
 int fsmc_phase_cycles(fsmc_ctx* ctx, uint64_t* out, size_t n)
 {
-  if (!ctx || !out || n > 8) {
+  if (!ctx || !out || n > 32) {
     return fail(ctx, FSMC_EINVAL, "bad argument");
   }
   FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   FSMC_HIP(ctx, hipMemcpy(out, ctx->dPhase, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  FSMC_HIP(ctx, hipMemset(ctx->dPhase, 0, 8 * sizeof(unsigned long long)));
+  FSMC_HIP(ctx, hipMemset(ctx->dPhase, 0, 32 * sizeof(unsigned long long)));
   return FSMC_OK;
 }
 

@@ -59,6 +59,7 @@ struct KParams {
   const float* U;
   const float* rowSets; // [rows][5][KP]: D | B | U | Ush | RR of one key side by side, Ush[k] = U[k-1] (packed steps)
   const float* RR;
+  const float* ghostMask; // [KP] 1.0f for the K real states, 0.0f for the padding states (padded family members)
   const int* stepRow; // [S] row of the step into site q (array mode); sequence mode: the site step, forward
   const int* rowGapF; // sequence mode only: rows of the half-step across the gap (q-1, q), forward
   const int* rowSiteB; //                     site step, backward (out of site q)
@@ -124,7 +125,11 @@ __device__ __forceinline__ f32x4 sload4(cfloat_p p, const int byteOff)
 __device__ __forceinline__ f32x8 sload8(cfloat_p p, const int byteOff)
 {
   f32x8 v = {};
+#if defined(FSMC_DIAG_NOSMEM)
+  FSMC_GCN_ASM("; no load %0 %1 %2" : "=s"(v) : "s"(p), "i"(byteOff));
+#else
   FSMC_GCN_ASM("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(p), "i"(byteOff));
+#endif
   return v;
 }
 // Scalar-cache warm-up.  A table row spans five 64-byte lines; most of them miss the 16-KB scalar cache (16 waves
@@ -191,7 +196,11 @@ template <> struct SV<16> {
   static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState)
   {
     f32x16 v = {};
+#if defined(FSMC_DIAG_NOSMEM) // timing experiment only (results are wrong): operands are whatever the registers hold
+    FSMC_GCN_ASM("; no load %0 %1 %2" : "=s"(v) : "s"(p), "i"(firstState * 4));
+#else
     FSMC_GCN_ASM("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "i"(firstState * 4));
+#endif
     return v;
   }
 };
@@ -200,7 +209,7 @@ __device__ __forceinline__ void swait(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
   FSMC_GCN_ASM(FSMC_SWAIT_INSN : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
 }
 
-#if defined(FSMC_PHASE_STAMPS)
+#if defined(FSMC_WAIT_STAMPS)
 #define FSMC_SWAIT(acc, ...)                                                                                           \
   do {                                                                                                                 \
     const long long t0_ = (long long)clock64();                                                                        \
@@ -253,10 +262,37 @@ template <int N> __device__ __forceinline__ EmisBlk<N> readEmis(const float4* e,
   EmisBlk<N> r;
 #pragma unroll
   for (int j = 0; j < N / 4; ++j) {
+#if defined(FSMC_DIAG_NOEMIS) // timing experiment only (results are wrong): no LDS read, the values are undefined
+    FSMC_GCN_ASM("; no read" : "=v"(r.v[j].x), "=v"(r.v[j].y), "=v"(r.v[j].z), "=v"(r.v[j].w) : "v"(e));
+#else
     r.v[j] = e[blk * (N / 4) + j];
+#endif
   }
   return r;
 }
+
+// Diagnostic builds only (never in the shipped library): where a wave's cycles go.
+//   -DFSMC_WAIT_STAMPS    cycles parked in the operand waits of the step functions
+//   -DFSMC_REGION_STAMPS  cycles per code region: FSMC_END(dg, id) charges the time since the previous stamp to region
+//                         id (s_memtime, low 32 bits; the accumulators are flushed once per group)
+constexpr int kDiagRegions = 16;
+struct Diag {
+  long long waitCycles = 0;
+#if defined(FSMC_REGION_STAMPS)
+  unsigned acc[kDiagRegions] = {};
+  unsigned last = 0;
+#endif
+};
+#if defined(FSMC_REGION_STAMPS)
+#define FSMC_END(dg, id)                                                                                               \
+  do {                                                                                                                 \
+    const unsigned now_ = (unsigned)__builtin_readcyclecounter();                                                      \
+    (dg).acc[id] += now_ - (dg).last;                                                                                  \
+    (dg).last = now_;                                                                                                  \
+  } while (0)
+#else
+#define FSMC_END(dg, id) ((void)0)
+#endif
 
 // One step of the backward recursion for one pair (HMM.cpp:957-1016, NO_SSE association).
 // b: beta of site pos+1 (scaled) on entry, beta of site pos (scaled) on exit.  w: scratch.
@@ -264,7 +300,7 @@ template <int N> __device__ __forceinline__ EmisBlk<N> readEmis(const float4* e,
 // SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:915-922).
 template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void beta_step_1(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                            cfloat_p Ur, cfloat_p RRr, const float4* e, long long& waitCycles)
+                                            cfloat_p Ur, cfloat_p RRr, const float4* e, Diag& dg)
 {
   typedef typename SV<kKB>::T SVec;
   const int NB = (K + kKB - 1) / kKB;
@@ -282,7 +318,7 @@ __device__ __forceinline__ void beta_step_1(const int K, float (&b)[KA], float (
       rr = SV<kKB>::load(RRr + blk * kKB);
       em = readEmis<kKB>(e, blk);
     }
-    FSMC_SWAIT(waitCycles, u, rr);
+    FSMC_SWAIT(dg.waitCycles, u, rr);
     SVec nu = u, nrr = rr;
     EmisBlk<kKB> nem = em;
     if (KT > 0) {
@@ -321,7 +357,7 @@ __device__ __forceinline__ void beta_step_1(const int K, float (&b)[KA], float (
       d = SV<kKB>::load(Dr + blk * kKB);
       bt = SV<kKB>::load(Br + blk * kKB);
     }
-    FSMC_SWAIT(waitCycles, d, bt);
+    FSMC_SWAIT(dg.waitCycles, d, bt);
     SVec nd = d, nbt = bt;
     if (KT > 0 && blk + 1 < NB) {
       nd = SV<kKB>::load(Dr + (blk + 1) * kKB);
@@ -361,7 +397,7 @@ __device__ __forceinline__ void beta_step_1(const int K, float (&b)[KA], float (
 // SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:760-767).
 template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void alpha_step_1(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                             cfloat_p Ur, cfloat_p cR, const float4* e, long long& waitCycles)
+                                             cfloat_p Ur, cfloat_p cR, const float4* e, Diag& dg)
 {
   typedef typename SV<kKBF>::T SVec;
   const int NB = (K + kKBF - 1) / kKBF;
@@ -386,7 +422,7 @@ __device__ __forceinline__ void alpha_step_1(const int K, float (&a)[KA], float 
       c4 = SV<kKBF>::load(cR + blk * kKBF);
       em = readEmis<kKBF>(e, blk);
     }
-    FSMC_SWAIT(waitCycles, d, bt, u, c4);
+    FSMC_SWAIT(dg.waitCycles, d, bt, u, c4);
     SVec nd = d, nbt = bt, nu = u, nc = c4;
     EmisBlk<kKBF> nem = em;
     if (KT > 0 && blk + 1 < NB) {
@@ -441,124 +477,246 @@ __device__ __forceinline__ void alpha_step_1(const int K, float (&a)[KA], float 
 // operation on the same operands as in the scalar step (no FMA, no re-association), so the results are
 // bit-identical; only ~7.5 instead of 11 VALU instructions are issued per state.
 //
+// Operand delivery.  One operand block = kKB (beta) / kKBF (alpha) states: the block's table values
+// (scalar loads into SGPRs, inline asm) AND this lane's emission values of the same states (LDS reads) are
+// requested together, a whole block ahead, right after the single wait that opens the block before.  That wait is the
+// s_waitcnt BUILTIN, not inline asm: the compiler's wait-count pass sees it, marks its own LDS reads complete and
+// inserts no counted lgkmcnt wait of its own inside a step.  (It cannot see the asm scalar loads, which share the
+// counter and return out of order: a counted wait it placed for an LDS value right behind a freshly issued prefetch
+// waited for that prefetch as well -- every block paid a full scalar-load latency.)
+//
+// Ghost states (GHOST = true: K < KT, KT a multiple of kKPad).  States K..KT-1 have zero table, emission and prior
+// entries; their values stay exactly +0 through every operation and a sum that adds +0 in state order is the same
+// sum.  The one exception, beta'[k] = (BL + D*vec) + BU = BL for a ghost, is multiplied by a 1/0 mask row (states of
+// the last operand block only) before the scaling sum -- x * 1.0f is exact.  The reference's boundary cases
+// (BU[K-1] = 0, no B term for the last state) come out of the same arithmetic: U*0 + RR*0 and B*0.
+//
 // Backward: the term U[k]*vec[k+1] of BU[k] is taken from T[m] = Ush[m]*vec[m] with Ush[m] = U[m-1]
 // (a second copy of the U table shifted by one state), so that both factors share a state index.
-// First operand block of a backward step, requested by the step before it (BetaHead): the descending pass opens
-// with a wait on operands that nothing can be overlapped with unless they were asked for during the previous step's
-// last block.  The previous step waits for them before it returns (after its scaling loop), so the values are final
-// when they cross the code between two steps.
-struct BetaHead {
+__device__ __forceinline__ void waitLgkm0()
+{
+  __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0), vmcnt / expcnt left alone (gfx9 encoding)
+}
+__device__ __forceinline__ void waitVm0()
+{
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+}
+// After a wait: the registers of the scalar loads it covered are final.  Input-only on purpose -- an in/out ("+s")
+// operand is a new value to the register allocator, which may then copy the load's destination into another
+// register IN FRONT of the wait (observed: s_mov_b64 of sixteen in-flight SGPRs).  What keeps the uses behind the
+// wait is the __builtin_amdgcn_sched_barrier(0) that follows every wait + prefetch group.
+template <typename V> __device__ __forceinline__ void landed(const V& a, const V& b)
+{
+  FSMC_GCN_ASM("" ::"s"(a), "s"(b));
+}
+template <typename V> __device__ __forceinline__ void landed(const V& a, const V& b, const V& c, const V& d)
+{
+  FSMC_GCN_ASM("" ::"s"(a), "s"(b), "s"(c), "s"(d));
+}
+template <typename V> __device__ __forceinline__ void landed(const V& a)
+{
+  FSMC_GCN_ASM("" ::"s"(a));
+}
+// The wait that opens an operand block.  The scheduling barrier right behind it keeps register copies the allocator
+// makes for the code below (post-RA scheduling included) from being hoisted in front of the wait.
+#if defined(FSMC_WAIT_STAMPS) // (costs more than the waits it measures: its own switch, next to FSMC_PHASE_STAMPS)
+#define FSMC_WAIT_OPERANDS(acc)                                                                                        \
+  do {                                                                                                                 \
+    const long long t0_ = (long long)clock64();                                                                        \
+    waitLgkm0();                                                                                                       \
+    (acc) += (long long)clock64() - t0_;                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  } while (0)
+#else
+#define FSMC_WAIT_OPERANDS(acc)                                                                                        \
+  do {                                                                                                                 \
+    waitLgkm0();                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  } while (0)
+#endif
+
+// Line warm-up generalised: COUNT (0..4) dwords, one per 64-byte line FIRST, FIRST+1, ... of the row at firstState.
+template <int FIRST, int COUNT> __device__ __forceinline__ void touchRow(Touched& t, cfloat_p p, const int firstState)
+{
+  constexpr int STEP = 16;
+  if constexpr (COUNT >= 4) {
+    touchLines<FIRST, STEP>(t, p, firstState);
+  } else if constexpr (COUNT == 3) {
+    FSMC_GCN_ASM("s_load_dword %0, %3, %4\n\ts_load_dword %1, %3, %5\n\ts_load_dword %2, %3, %6"
+                 : "=&s"(t.r[0]), "=&s"(t.r[1]), "=&s"(t.r[2])
+                 : "s"(p), "i"((firstState + FIRST * STEP) * 4), "i"((firstState + (FIRST + 1) * STEP) * 4),
+                   "i"((firstState + (FIRST + 2) * STEP) * 4));
+  } else if constexpr (COUNT == 2) {
+    FSMC_GCN_ASM("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4"
+                 : "=&s"(t.r[0]), "=&s"(t.r[1])
+                 : "s"(p), "i"((firstState + FIRST * STEP) * 4), "i"((firstState + (FIRST + 1) * STEP) * 4));
+  } else if constexpr (COUNT == 1) {
+    FSMC_GCN_ASM("s_load_dword %0, %1, %2" : "=&s"(t.r[0]) : "s"(p), "i"((firstState + FIRST * STEP) * 4));
+  }
+}
+template <int COUNT> __device__ __forceinline__ void heldRow(const Touched& t)
+{
+  if constexpr (COUNT >= 4) {
+    FSMC_GCN_ASM("" ::"s"(t.r[0]), "s"(t.r[1]), "s"(t.r[2]), "s"(t.r[3]));
+  } else if constexpr (COUNT == 3) {
+    FSMC_GCN_ASM("" ::"s"(t.r[0]), "s"(t.r[1]), "s"(t.r[2]));
+  } else if constexpr (COUNT == 2) {
+    FSMC_GCN_ASM("" ::"s"(t.r[0]), "s"(t.r[1]));
+  } else if constexpr (COUNT == 1) {
+    FSMC_GCN_ASM("" ::"s"(t.r[0]));
+  }
+}
+
+// What a backward step has in flight when it opens: its first operand block (the top states of Ush and RR), the
+// warm-up of those rows' other lines and the emission values of the same states.  Requested by beta_issue_pk ahead of
+// operand-free work (the scaling multiply and the row store of the step before), consumed by beta_core_pk.
+template <int KT> struct BetaOps {
   typename SV<kKB>::T u, rr;
+  Touched tu, trr;
+  EmisBlk<kKB> em;
 };
 
-template <int KT, int KA, bool SCALE = true>
-__device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfloat_p rowSet, const float4* e,
-                                             long long& waitCycles, BetaHead& head, cfloat_p nextRowSet)
+template <int KT> __device__ __forceinline__ void beta_issue_pk(BetaOps<KT>& o, cfloat_p rowSet, const float4* e)
+{
+  constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
+  constexpr int NB = (KT + kKB - 1) / kKB;
+  constexpr int NLINES = KPc / 16;
+  o.u = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (NB - 1) * kKB);
+  o.rr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (NB - 1) * kKB);
+  if constexpr (kTouch) {
+    touchRow<0, NLINES - 1>(o.tu, rowSet, kRowUsh * KPc);
+    touchRow<0, NLINES - 1>(o.trr, rowSet, kRowRR * KPc);
+  }
+  o.em = readEmis<kKB>(e, NB - 1);
+}
+
+// The recurrences of one backward step: on entry b = beta of site pos+1 (scaled), on exit w = the un-normalised
+// beta of site pos and the return value its sum over the states (k ascending from 0.f); b is used up.
+template <int KT, int KA, bool GHOST>
+__device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], BetaOps<KT>& ops, cfloat_p rowSet,
+                                              const float4* e, cfloat_p ghostMask, Diag& dg)
 {
   constexpr int K = KT;
   // the five table rows of one key sit side by side (RowSet): one base register, block offsets as immediates
   constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
   typedef typename SV<kKB>::T SVec;
-  constexpr int NB = (K + kKB - 1) / kKB; // operand blocks (scalar loads, one block ahead)
-  constexpr int R = kKB / 8;              // emission sub-blocks of 8 states per operand block
-  constexpr int NSB = (K + 7) / 8;
-  static_assert(!kTouch || (KPc == 80 && K > 64), "line warm-up is laid out for rows of five 64-byte lines");
-  SVec u = head.u, rr = head.rr; // requested and waited for by betaHeadPrime or by the previous step
-  Touched tu, trr, td, tbt;
-  SVec nu = u, nrr = rr;
-  EmisBlk<8> em = readEmis<8>(e, NSB - 1);
-  SVec d, bt;
+  constexpr int NB = (K + kKB - 1) / kKB; // operand blocks (scalar loads + emission values, one block ahead)
+  constexpr int R = kKB / 8;              // sub-blocks of 8 states per operand block
+  constexpr int NLINES = KPc / 16;
+  static_assert(kKB == 16, "line warm-up and ghost masking are laid out for operand blocks of one 64-byte line");
+  static_assert(!GHOST || K % kKB == 0, "ghost padding fills whole operand blocks");
+  // (no initialisers: a copy of a register whose scalar load is still in flight would read garbage; every one of
+  //  these is assigned behind a wait before it is read -- the block loops are fully unrolled)
+  SVec u, rr, nu, nrr;
+  EmisBlk<kKB> em, nem;
+  SVec d, bt, nd, nbt, mk;
+  Touched td, tbt;
   float tcarry = 0.f; // T of the first state of the sub-block above
 #pragma unroll
-  for (int sb = NSB - 1; sb >= 0; --sb) {
-    const int blk = sb / R;
-    const int o = (sb % R) * 8; // offset of this sub-block inside the operand block
-    if (sb == NSB - 1 || sb % R == R - 1) {
-      // entering operand block blk: its loads were issued a whole block ago; request the next one
-      if (sb != NSB - 1) {
-        FSMC_SWAIT(waitCycles, nu, nrr);
-        u = nu;
-        rr = nrr;
+  for (int blk = NB - 1; blk >= 0; --blk) {
+    FSMC_WAIT_OPERANDS(dg.waitCycles);
+    if (blk == NB - 1) {
+      landed(ops.u, ops.rr);
+      if constexpr (kTouch) {
+        heldRow<NLINES - 1>(ops.tu);
+        heldRow<NLINES - 1>(ops.trr);
       }
-      if (blk > 0) {
-        nu = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (blk - 1) * kKB);
-        nrr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (blk - 1) * kKB);
-      } else {
-        d = SV<kKB>::loadAt(rowSet, kRowD * KPc);
-        bt = SV<kKB>::loadAt(rowSet, kRowB * KPc);
-        if constexpr (kTouch) {
-          touchLines<1>(td, rowSet, kRowD * KPc);
-          touchLines<1>(tbt, rowSet, kRowB * KPc);
-        }
-      }
+      u = ops.u;
+      rr = ops.rr;
+      em = ops.em;
+    } else {
+      landed(nu, nrr);
+      u = nu;
+      rr = nrr;
+      em = nem;
     }
-    EmisBlk<8> nem = em;
-    if (sb > 0) {
-      nem = readEmis<8>(e, sb - 1);
+    if (blk > 0) {
+      nu = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (blk - 1) * kKB);
+      nrr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (blk - 1) * kKB);
+      nem = readEmis<kKB>(e, blk - 1);
+    } else {
+      d = SV<kKB>::loadAt(rowSet, kRowD * KPc);
+      bt = SV<kKB>::loadAt(rowSet, kRowB * KPc);
+      if constexpr (kTouch) {
+        touchRow<1, NLINES - 1>(td, rowSet, kRowD * KPc);
+        touchRow<1, NLINES - 1>(tbt, rowSet, kRowB * KPc);
+      }
+      if constexpr (GHOST && NB == 1) {
+        mk = SV<kKB>::loadAt(ghostMask, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    float T[9];
-    T[8] = tcarry;
-    // vec[k] = beta[k]*e[k] (kept in b), T[k] = U[k-1]*vec[k]
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      const int k = sb * 8 + i;
-      if (k + 1 < K) {
-        f32x2 v = {b[k], b[k + 1]};
-        v = v * em.pair(i);
-        const f32x2 t = pairOf(u, o + i) * v;
-        b[k] = v.x;
-        b[k + 1] = v.y;
-        T[i] = t.x;
-        T[i + 1] = t.y;
-      } else if (k < K) {
-        b[k] = b[k] * em.at(i);
-        T[i] = u[o + i] * b[k];
+    for (int sbi = R - 1; sbi >= 0; --sbi) {
+      const int sb = blk * R + sbi;
+      const int o = sbi * 8; // offset of this sub-block inside the operand block
+      if (sb * 8 >= K) {
+        continue;
       }
-    }
-    // BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1], BU[K-1] = 0 (HMM.cpp:986-1005)
+      float T[9];
+      T[8] = tcarry;
+      // vec[k] = beta[k]*e[k] (kept in b), T[k] = U[k-1]*vec[k]
 #pragma unroll
-    for (int i = 7; i >= 0; --i) {
-      const int k = sb * 8 + i;
-      if (k < K) {
-        if (k == K - 1) {
-          w[k] = 0.f;
-        } else {
-          w[k] = T[i + 1] + rr[o + i] * w[k + 1];
+      for (int i = 0; i < 8; i += 2) {
+        const int k = sb * 8 + i;
+        if (k + 1 < K) {
+          f32x2 v = {b[k], b[k + 1]};
+          v = v * em.pair(o + i);
+          const f32x2 t = pairOf(u, o + i) * v;
+          b[k] = v.x;
+          b[k + 1] = v.y;
+          T[i] = t.x;
+          T[i + 1] = t.y;
+        } else if (k < K) {
+          b[k] = b[k] * em.at(o + i);
+          T[i] = u[o + i] * b[k];
         }
       }
+      // BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1], BU[K-1] = 0 (HMM.cpp:986-1005)
+#pragma unroll
+      for (int i = 7; i >= 0; --i) {
+        const int k = sb * 8 + i;
+        if (k < K) {
+          if (k == K - 1) {
+            w[k] = 0.f;
+          } else {
+            w[k] = T[i + 1] + rr[o + i] * w[k + 1];
+          }
+        }
+      }
+      tcarry = T[0];
     }
-    tcarry = T[0];
-    em = nem;
   }
+  FSMC_END(dg, 2);
   // ascending: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k]
   float BL = 0.f;
   float sum = 0.f;
-  SVec nd = d, nbt = bt;
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
+    FSMC_WAIT_OPERANDS(dg.waitCycles);
     if (blk > 0) {
-      FSMC_SWAIT(waitCycles, nd, nbt);
+      landed(nd, nbt);
       d = nd;
       bt = nbt;
     } else {
-      FSMC_SWAIT(waitCycles, d, bt);
+      landed(d, bt);
       if constexpr (kTouch) {
-        holdTouched(td);
-        holdTouched(tbt);
+        heldRow<NLINES - 1>(td);
+        heldRow<NLINES - 1>(tbt);
+      }
+    }
+    if constexpr (GHOST) {
+      if (blk == NB - 1) {
+        landed(mk);
       }
     }
     if (blk + 1 < NB) {
       nd = SV<kKB>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKB);
       nbt = SV<kKB>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKB);
-    } else {
-      // last block: the next step's first operand block and the lines of its descending pass (always requested --
-      // a branch here would split the step's single basic block; without a next step the caller passes this row)
-      head.u = SV<kKB>::loadAt(nextRowSet, kRowUsh * KPc + (NB - 1) * kKB);
-      head.rr = SV<kKB>::loadAt(nextRowSet, kRowRR * KPc + (NB - 1) * kKB);
-      if constexpr (kTouch) {
-        touchLines<0>(tu, nextRowSet, kRowUsh * KPc);
-        touchLines<0>(trr, nextRowSet, kRowRR * KPc);
+      if constexpr (GHOST) {
+        if (blk + 1 == NB - 1) {
+          mk = SV<kKB>::loadAt(ghostMask, (NB - 1) * kKB);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -575,6 +733,11 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
         f32x2 x = bl + dv;
         const f32x2 bu = {w[k], w[k + 1]};
         x = x + bu;
+        if constexpr (GHOST) {
+          if (blk == NB - 1) {
+            x = x * pairOf(mk, i);
+          }
+        }
         w[k] = x.x;
         w[k + 1] = x.y;
         sum = sum + x.x;
@@ -589,49 +752,45 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
       }
     }
   }
-  if constexpr (SCALE) {
-    const float c = 1.0f / sum;
-    const f32x2 cc = {c, c};
+  FSMC_END(dg, 3);
+  return sum;
+}
+
+// The operand-free tail of a step (HmmUtils.cpp:102-151: scal = 1.0f/sum, vec *= scal): v = w * (1.0f / sum).
+// With sum = 1.0f it is an exact copy (a loaded checkpoint, the un-normalised half-steps of sequence mode).
+template <int KT, int KA> __device__ __forceinline__ void scale_pk(float (&v)[KA], const float (&w)[KA], const float sum)
+{
+  constexpr int K = KT;
+  const float c = 1.0f / sum;
+  const f32x2 cc = {c, c};
 #pragma unroll
-    for (int k = 0; k < K; k += 2) {
-      if (k + 1 < K) {
-        const f32x2 x = {w[k], w[k + 1]};
-        const f32x2 y = x * cc;
-        b[k] = y.x;
-        b[k + 1] = y.y;
-      } else {
-        b[k] = w[k] * c;
-      }
+  for (int k = 0; k < K; k += 2) {
+    if (k + 1 < K) {
+      const f32x2 x = {w[k], w[k + 1]};
+      const f32x2 y = x * cc;
+      v[k] = y.x;
+      v[k + 1] = y.y;
+    } else {
+      v[k] = w[k] * c;
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      b[k] = w[k];
-    }
-  }
-  FSMC_SWAIT(waitCycles, head.u, head.rr);
-  if constexpr (kTouch) {
-    holdTouched(tu);
-    holdTouched(trr);
   }
 }
 
-// The first operand block of a backward step that no step precedes (start of a sweep, a recomputed row).
-template <int KT> __device__ __forceinline__ void betaHeadPrime(BetaHead& head, cfloat_p rowSet, long long& waitCycles)
+// A whole backward step in one piece (the sequence-mode passes and the recomputed rows of beta stride 2).
+template <int KT, int KA, bool SCALE, bool GHOST>
+__device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfloat_p rowSet, const float4* e,
+                                             cfloat_p ghostMask, Diag& dg)
 {
-  constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
-  constexpr int NB = (KT + kKB - 1) / kKB;
-  head.u = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (NB - 1) * kKB);
-  head.rr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (NB - 1) * kKB);
-  Touched tu, trr;
-  if constexpr (kTouch) {
-    touchLines<0>(tu, rowSet, kRowUsh * KPc);
-    touchLines<0>(trr, rowSet, kRowRR * KPc);
-  }
-  FSMC_SWAIT(waitCycles, head.u, head.rr);
-  if constexpr (kTouch) {
-    holdTouched(tu);
-    holdTouched(trr);
+  BetaOps<KT> ops;
+  beta_issue_pk<KT>(ops, rowSet, e);
+  const float sum = beta_core_pk<KT, KA, GHOST>(b, w, ops, rowSet, e, ghostMask, dg);
+  if constexpr (SCALE) {
+    scale_pk<KT, KA>(b, w, sum);
+  } else {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      b[k] = w[k];
+    }
   }
 }
 
@@ -639,26 +798,26 @@ template <int KT> __device__ __forceinline__ void betaHeadPrime(BetaHead& head, 
 // other products of state k; alphaC[0] is never used (HMM.cpp:799-830).
 template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cfloat_p rowSet, cfloat_p cR,
-                                              const float4* e, long long& waitCycles)
+                                              const float4* e, Diag& dg)
 {
   constexpr int K = KT;
   constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
   static_assert(K >= 2, "packed step needs at least two states");
   typedef typename SV<kKBF>::T SVec;
-  constexpr int NB = (K + kKBF - 1) / kKBF; // operand blocks
-  constexpr int R = kKBF / 4;               // emission sub-blocks of 4 states per operand block
-  constexpr int NSB = (K + 3) / 4;
+  constexpr int NB = (K + kKBF - 1) / kKBF; // operand blocks (scalar loads + emission values, one block ahead)
+  constexpr int NLINES = KPc / 16;
   SVec d = SV<kKBF>::loadAt(rowSet, kRowD * KPc), bt = SV<kKBF>::loadAt(rowSet, kRowB * KPc),
        u = SV<kKBF>::loadAt(rowSet, kRowU * KPc), c4 = SV<kKBF>::loadAt(cR, 0);
   Touched td, tbt, tu;
   if constexpr (kTouch) {
-    touchLines<1>(td, rowSet, kRowD * KPc);
-    touchLines<1>(tbt, rowSet, kRowB * KPc);
-    touchLines<1>(tu, rowSet, kRowU * KPc);
+    touchRow<1, NLINES - 1>(td, rowSet, kRowD * KPc);
+    touchRow<1, NLINES - 1>(tbt, rowSet, kRowB * KPc);
+    touchRow<1, NLINES - 1>(tu, rowSet, kRowU * KPc);
   }
-  SVec nd = d, nbt = bt, nu = u, nc = c4;
-  EmisBlk<4> em = readEmis<4>(e, 0);
+  SVec nd, nbt, nu, nc; // (assigned behind a wait before they are read; see beta_core_pk)
+  EmisBlk<kKBF> em = readEmis<kKBF>(e, 0), nem;
   __builtin_amdgcn_sched_barrier(0);
+  // operand-free: alphaC[k+1] = sum_{i>k} alpha[i], accumulated from the top (HMM.cpp:799-814)
   w[K - 2] = a[K - 1];
 #pragma unroll
   for (int k = K - 2; k >= 1; --k) {
@@ -666,49 +825,45 @@ __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cf
   }
   float AU = 0.f;
   float sum = 0.f;
+  FSMC_END(dg, 5);
 #pragma unroll
-  for (int sb = 0; sb < NSB; ++sb) {
-    const int blk = sb / R;
-    const int o = (sb % R) * 4;
-    if (sb % R == 0) {
-      if (sb > 0) {
-        FSMC_SWAIT(waitCycles, nd, nbt, nu, nc);
-        d = nd;
-        bt = nbt;
-        u = nu;
-        c4 = nc;
-      } else {
-        FSMC_SWAIT(waitCycles, d, bt, u, c4);
-        if constexpr (kTouch) {
-          holdTouched(td);
-          holdTouched(tbt);
-          holdTouched(tu);
-        }
-      }
-      if (blk + 1 < NB) {
-        nd = SV<kKBF>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKBF);
-        nbt = SV<kKBF>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKBF);
-        nu = SV<kKBF>::loadAt(rowSet, kRowU * KPc + (blk + 1) * kKBF);
-        nc = SV<kKBF>::loadAt(cR, (blk + 1) * kKBF);
+  for (int blk = 0; blk < NB; ++blk) {
+    FSMC_WAIT_OPERANDS(dg.waitCycles);
+    if (blk > 0) {
+      landed(nd, nbt, nu, nc);
+      d = nd;
+      bt = nbt;
+      u = nu;
+      c4 = nc;
+      em = nem;
+    } else {
+      landed(d, bt, u, c4);
+      if constexpr (kTouch) {
+        heldRow<NLINES - 1>(td);
+        heldRow<NLINES - 1>(tbt);
+        heldRow<NLINES - 1>(tu);
       }
     }
-    EmisBlk<4> nem = em;
-    if (sb + 1 < NSB) {
-      nem = readEmis<4>(e, sb + 1);
+    if (blk + 1 < NB) {
+      nd = SV<kKBF>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKBF);
+      nbt = SV<kKBF>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKBF);
+      nu = SV<kKBF>::loadAt(rowSet, kRowU * KPc + (blk + 1) * kKBF);
+      nc = SV<kKBF>::loadAt(cR, (blk + 1) * kKBF);
+      nem = readEmis<kKBF>(e, blk + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 4; i += 2) {
-      const int k = sb * 4 + i;
+    for (int i = 0; i < kKBF; i += 2) {
+      const int k = blk * kKBF + i;
       if (k + 1 < K - 1) {
         const f32x2 av = {a[k], a[k + 1]};
-        const f32x2 da = pairOf(d, o + i) * av;
-        const f32x2 ua = pairOf(u, o + i) * av;
+        const f32x2 da = pairOf(d, i) * av;
+        const f32x2 ua = pairOf(u, i) * av;
         const f32x2 ac = {w[k], w[k + 1]};
-        const f32x2 bw = pairOf(bt, o + i) * ac;
+        const f32x2 bw = pairOf(bt, i) * ac;
         f32x2 au;
         au.x = AU;
-        au.y = ua.x + c4[o + i] * AU; // AU of state k+1
+        au.y = ua.x + c4[i] * AU; // AU of state k+1
         f32x2 term = au + da;
         term = term + bw;
         const f32x2 ov = em.pair(i) * term;
@@ -716,47 +871,36 @@ __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cf
         w[k + 1] = ov.y;
         sum = sum + ov.x;
         sum = sum + ov.y;
-        AU = ua.y + c4[o + i + 1] * au.y; // AU of state k+2
+        AU = ua.y + c4[i + 1] * au.y; // AU of state k+2
       } else {
 #pragma unroll
         for (int ii = i; ii < i + 2; ++ii) {
-          const int kk = sb * 4 + ii;
+          const int kk = blk * kKBF + ii;
           if (kk < K) {
-            float term = AU + d[o + ii] * a[kk];
+            float term = AU + d[ii] * a[kk];
             if (kk < K - 1) {
-              term = term + bt[o + ii] * w[kk];
+              term = term + bt[ii] * w[kk];
             }
             w[kk] = em.at(ii) * term;
             sum = sum + w[kk];
             if (kk < K - 1) {
-              AU = u[o + ii] * a[kk] + c4[o + ii] * AU;
+              AU = u[ii] * a[kk] + c4[ii] * AU;
             }
           }
         }
       }
     }
-    em = nem;
   }
+  FSMC_END(dg, 6);
   if constexpr (SCALE) {
-    const float c = 1.0f / sum;
-    const f32x2 cc = {c, c};
-#pragma unroll
-    for (int k = 0; k < K; k += 2) {
-      if (k + 1 < K) {
-        const f32x2 x = {w[k], w[k + 1]};
-        const f32x2 y = x * cc;
-        a[k] = y.x;
-        a[k + 1] = y.y;
-      } else {
-        a[k] = w[k] * c;
-      }
-    }
+    scale_pk<KT, KA>(a, w, sum);
   } else {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       a[k] = w[k];
     }
   }
+  FSMC_END(dg, 7);
 }
 
 
@@ -770,46 +914,40 @@ constexpr bool kPacked = true;
 // The tables as the kernel addresses them: `row` selects the key.  Packed steps read the RowSet copy, the generic
 // (runtime-K) steps the four separate tables.
 struct Tables {
-  cfloat_p D, B, U, RR, rowSets, cR;
+  cfloat_p D, B, U, RR, rowSets, cR, ghostMask;
   int KP;
 };
 
-// nextRow: key of the backward step that follows immediately (its first operands are requested ahead through
-// `head`), or -1.
+// compile-time K that is a whole number of operand blocks = a padded family member (K <= KT real states)
+template <int KT> constexpr bool kGhost = KT > 0 && KT % kKPad == 0;
+
+template <int KT> __device__ __forceinline__ cfloat_p rowSetOf(const Tables& t, const int row)
+{
+  constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
+  return t.rowSets + (size_t)row * (kRowSetParts * KPc);
+}
+
 template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], const Tables& t, const int row,
-                                          const float4* e, long long& waitCycles, BetaHead& head,
-                                          const bool primed = false, const int nextRow = -1)
+                                          const float4* e, Diag& dg)
 {
   if constexpr (KT > 0 && kPacked) {
-    constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
-    const cfloat_p rs = t.rowSets + (size_t)row * (kRowSetParts * KPc);
-#if defined(FSMC_NO_HEAD)
-    betaHeadPrime<KT>(head, rs, waitCycles);
-    beta_step_pk<KT, KA, SCALE>(b, w, rs, e, waitCycles, head, rs);
-#else
-    if (!primed) {
-      betaHeadPrime<KT>(head, rs, waitCycles);
-    }
-    beta_step_pk<KT, KA, SCALE>(b, w, rs, e, waitCycles, head,
-                                t.rowSets + (size_t)(nextRow < 0 ? row : nextRow) * (kRowSetParts * KPc));
-#endif
+    beta_step_pk<KT, KA, SCALE, kGhost<KT>>(b, w, rowSetOf<KT>(t, row), e, t.ghostMask, dg);
   } else {
     const size_t o = (size_t)row * t.KP;
-    beta_step_1<KT, KA, SCALE>(K, b, w, t.D + o, t.B + o, t.U + o, t.RR + o, e, waitCycles);
+    beta_step_1<KT, KA, SCALE>(K, b, w, t.D + o, t.B + o, t.U + o, t.RR + o, e, dg);
   }
 }
 
 template <int KT, int KA, bool SCALE = true>
 __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], const Tables& t, const int row,
-                                           const float4* e, long long& waitCycles)
+                                           const float4* e, Diag& dg)
 {
   if constexpr (KT > 0 && kPacked) {
-    constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
-    alpha_step_pk<KT, KA, SCALE>(a, w, t.rowSets + (size_t)row * (kRowSetParts * KPc), t.cR, e, waitCycles);
+    alpha_step_pk<KT, KA, SCALE>(a, w, rowSetOf<KT>(t, row), t.cR, e, dg);
   } else {
     const size_t o = (size_t)row * t.KP;
-    alpha_step_1<KT, KA, SCALE>(K, a, w, t.D + o, t.B + o, t.U + o, t.cR, e, waitCycles);
+    alpha_step_1<KT, KA, SCALE>(K, a, w, t.D + o, t.B + o, t.U + o, t.cR, e, dg);
   }
 }
 
@@ -836,12 +974,13 @@ __device__ __forceinline__ void alpha_init(const int K, float (&a)[KA], cfloat_p
 }
 
 // beta at the last site of the window: all ones, scaled (HMM.cpp:887-897).
-template <int KT, int KA> __device__ __forceinline__ void beta_init(const int K, float (&b)[KA])
+// (Kreal < K for a padded family member: the ghost states start at +0 and add +0 to the sum)
+template <int KT, int KA> __device__ __forceinline__ void beta_init(const int K, const int Kreal, float (&b)[KA])
 {
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    b[k] = 1.0f;
+    b[k] = (!kGhost<KT> || k < Kreal) ? 1.0f : 0.f;
     sum = sum + b[k];
   }
   const float c = 1.0f / sum;
@@ -853,8 +992,22 @@ template <int KT, int KA> __device__ __forceinline__ void beta_init(const int K,
 
 // A K-vector of one wave lives in HBM as [K/4][64 lanes] float4: one coalesced 1-KiB row per
 // group of four states (global_store/load_dwordx4).
-template <int KT, int KA> __device__ __forceinline__ void store_vec(const int K, float4* dst, const float (&v)[KA])
+// Addressing: `row` is the WAVE-UNIFORM address of the vector (lane 0, states 0..3) and laneOff = 16 * lane.  Each
+// access is then "scalar base + 32-bit lane offset + immediate" (the saddr form of the global instructions): no
+// per-row 64-bit address vectors.  (Kept as per-lane pointers the compiler hoisted eighteen of them out of the site
+// loops, spilled them, and reloaded each in front of its store behind an s_waitcnt vmcnt(0) -- every row went out
+// as fifteen serialised memory round trips, which was 50 % of the kernel's time.)
+__device__ __forceinline__ const char* uniformPtr(const void* p)
 {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+template <int KT, int KA>
+__device__ __forceinline__ void store_vec(const int K, float4* row, const unsigned laneOff, const float (&v)[KA])
+{
+  char* const base = const_cast<char*>(uniformPtr(row));
   const int K4 = (K + 3) >> 2;
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) {
@@ -865,16 +1018,19 @@ template <int KT, int KA> __device__ __forceinline__ void store_vec(const int K,
     o.w = (4 * k4 + 3 < K) ? v[4 * k4 + 3] : 0.f;
     // streamed once, read back once: keep it from evicting the model tables out of L2
     const f32x4 ov = {o.x, o.y, o.z, o.w};
-    __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(&dst[(size_t)k4 * kWave]));
+    __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff));
   }
 }
 
-template <int KT, int KA> __device__ __forceinline__ void load_vec(const int K, const float4* src, float (&v)[KA])
+template <int KT, int KA>
+__device__ __forceinline__ void load_vec(const int K, const float4* row, const unsigned laneOff, float (&v)[KA])
 {
+  const char* const base = uniformPtr(row);
   const int K4 = (K + 3) >> 2;
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) {
-    const f32x4 ov = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(&src[(size_t)k4 * kWave]));
+    const f32x4 ov = __builtin_nontemporal_load(
+        reinterpret_cast<const f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff));
     const float4 o = make_float4(ov.x, ov.y, ov.z, ov.w);
     v[4 * k4] = o.x;
     if (4 * k4 + 1 < K) v[4 * k4 + 1] = o.y;
@@ -940,6 +1096,9 @@ template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF>
 __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 {
   static_assert(!HALF || (!SEQ && MODE == kModeIbd), "beta stride 2 is built for the array-mode IBD decode");
+  // array mode with a compile-time K: the backward loops are rotated (operand-free step tails overlap the next
+  // step's first operand requests)
+  constexpr bool kRotate = KT > 0 && kPacked && !SEQ;
   constexpr int KA = KT > 0 ? KT : kMaxGenericK;
   constexpr int K4A = (KA + 3) / 4;
   constexpr int E4A = ((KA + kKPad - 1) / kKPad) * (kKPad / 4); // float4 per emission row (rows padded to kKPad)
@@ -956,7 +1115,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   const int lane = threadIdx.x;
   const cfloat_p tD = (cfloat_p)p.D, tB = (cfloat_p)p.B, tU = (cfloat_p)p.U, tRR = (cfloat_p)p.RR;
   const cfloat_p tPi = (cfloat_p)p.pi, tCR = (cfloat_p)p.cR, tExpT = (cfloat_p)p.expT;
-  const Tables tabs = {tD, tB, tU, tRR, (cfloat_p)p.rowSets, tCR, KP};
+  const Tables tabs = {tD, tB, tU, tRR, (cfloat_p)p.rowSets, tCR, (cfloat_p)p.ghostMask, KP};
   const cint_p tStepRow = (cint_p)p.stepRow;
   const cint_p tRowGapF = (cint_p)p.rowGapF, tRowSiteB = (cint_p)(SEQ ? p.rowSiteB : p.stepRow),
                tRowGapB = (cint_p)p.rowGapB;
@@ -968,8 +1127,15 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   const int C = p.chunk;
   // per-state posterior sums of the open segments (TRACK), one column per lane
   float4* const spsMem = saveS + threadIdx.x;
+  const unsigned laneOff = threadIdx.x * (unsigned)sizeof(float4); // this lane's byte offset inside a 1-KiB row
   // chunk-buffer slot of the row stored for the site at offset rel of its chunk
+#if defined(FSMC_DIAG_SAMEROW)
+  // timing experiment only (results are wrong): every stored row lands on the chunk buffer's first slot, so the
+  // instruction stream is unchanged but the beta stream stays in the caches instead of going through HBM
+  auto slotOf = [](const int rel) -> size_t { return (size_t)(rel & 0); };
+#else
   auto slotOf = [](const int rel) -> size_t { return (size_t)(HALF ? (rel >> 1) : rel); };
+#endif
 
   struct EmisRegs {
     float4 v[NL];
@@ -1049,7 +1215,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     };
 
     float w[KA];
-    long long cycW = 0; // cycles parked in operand waits (diagnostic builds only)
+    Diag cycW; // diagnostic builds only: cycles parked in operand waits, cycles per code region
+#if defined(FSMC_REGION_STAMPS)
+    cycW.last = (unsigned)__builtin_readcyclecounter();
+#endif
 #if defined(FSMC_PHASE_STAMPS)
     // diagnostic build only: where a group's wall time goes (never enabled in the shipped library)
     long long cycB = 0, cycR = 0, cycA = 0;
@@ -1071,8 +1240,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     auto betaGapStep = [&](float (&b)[KA], const int q, const EmisRegs& rows) {
       commitEmis(q, rows);
       const int row = tRowGapB[q];
-      BetaHead head;
-      beta_step<KT, KA, false>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW, head);
+      beta_step<KT, KA, false>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW);
     };
     auto betaSeqStep = [&](float (&b)[KA], const int pos) {
       const int q = pos + 1;
@@ -1083,8 +1251,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       }
       const int c = obsClass(q);
       const int row = tRowSiteB[q];
-      BetaHead head;
-      beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW, head);
+      beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
       if (gap) {
         betaGapStep(b, pos, ev);
       }
@@ -1093,19 +1260,24 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     // ------------------------------------------------------------------ pass B
     {
       float b[KA];
-      beta_init<KT, KA>(K, b);
+      if constexpr (!kRotate) {
+        beta_init<KT, KA>(K, p.K, b);
+      }
+      // Checkpoints (multi-chunk windows): beta at the first site of every chunk but the first -- slot j for site
+      // from + j*C -- and at aEnd (slot nChunks) when the alpha sweep stops short of the window.  Pass B walks down,
+      // so the next checkpoint is a countdown (no integer division per site).
+      int ckJ = (aEnd < to) ? nChunks : nChunks - 1;
+      int ckPos = (aEnd < to) ? aEnd : from + ckJ * C;
       auto afterBeta = [&](const int pos) {
         if (single) {
           const int rel = pos - from;
           if (pos < aEnd && (!HALF || (rel & 1) || pos == aEnd - 1)) {
-            store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4 + lane, b);
+            store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4, laneOff, b);
           }
-        } else {
-          const int rel = pos - from;
-          if (rel > 0 && pos <= aEnd && (rel % C == 0 || pos == aEnd)) {
-            const int j = (pos == aEnd) ? nChunks : rel / C;
-            store_vec<KT, KA>(K, ckpt + (size_t)j * vecF4 + lane, b);
-          }
+        } else if (pos == ckPos && ckJ >= 1) {
+          store_vec<KT, KA>(K, ckpt + (size_t)ckJ * vecF4, laneOff, b);
+          ckJ -= 1;
+          ckPos = from + ckJ * C;
         }
       };
       if constexpr (SEQ) {
@@ -1113,7 +1285,9 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           betaGapStep(b, to - 1, prefetchEmis(to - 1));
         }
       }
-      afterBeta(to - 1);
+      if constexpr (!kRotate) {
+        afterBeta(to - 1);
+      }
       if constexpr (SEQ) {
         for (int pos = to - 2; pos >= from; --pos) {
           betaSeqStep(b, pos);
@@ -1126,21 +1300,50 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           ev = prefetchEmis(to - 1);
           rowNext = tStepRow[to - 1];
         }
-        BetaHead head;
-        bool primed = false;
-        for (int pos = to - 2; pos >= from; --pos) {
-          const int q = pos + 1;
-          commitEmis(q, ev);
-          const int row = rowNext;
-          rowNext = -1;
-          if (pos - 1 >= from) {
-            ev = prefetchEmis(q - 1);
-            rowNext = tStepRow[q - 1];
+        if constexpr (kRotate) {
+          // Rotated loop: the operand-free tail of a step (1/sum, the scaling multiply, the row store) runs while
+          // the next step's first operands are in flight.  Carried from step to step: the un-normalised row w and
+          // its sum; beta_init is the same thing with w = 1.0f (sum = K by sequential adds, HMM.cpp:887-897).
+          float bsum = 0.f;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            w[k] = (!kGhost<KT> || k < p.K) ? 1.0f : 0.f;
+            bsum = bsum + w[k];
           }
-          const int c = obsClass(q);
-          beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW, head, primed, rowNext);
-          primed = rowNext >= 0;
-          afterBeta(pos);
+          for (int pos = to - 2; pos >= from; --pos) {
+            const int q = pos + 1;
+            commitEmis(q, ev);
+            const int row = rowNext;
+            if (pos - 1 >= from) {
+              ev = prefetchEmis(q - 1);
+              rowNext = tStepRow[q - 1];
+            }
+            const int c = obsClass(q);
+            const float4* e = &emisLds[q & 1][c * E4];
+            const cfloat_p rs = rowSetOf<KT>(tabs, row);
+            BetaOps<KT> ops;
+            beta_issue_pk<KT>(ops, rs, e);
+            FSMC_END(cycW, 0);
+            scale_pk<KT, KA>(b, w, bsum); // beta of site q, final
+            afterBeta(q);
+            FSMC_END(cycW, 1);
+            bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, e, tabs.ghostMask, cycW);
+          }
+          scale_pk<KT, KA>(b, w, bsum);
+          afterBeta(from);
+        } else {
+          for (int pos = to - 2; pos >= from; --pos) {
+            const int q = pos + 1;
+            commitEmis(q, ev);
+            const int row = rowNext;
+            if (pos - 1 >= from) {
+              ev = prefetchEmis(q - 1);
+              rowNext = tStepRow[q - 1];
+            }
+            const int c = obsClass(q);
+            beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+            afterBeta(pos);
+          }
         }
       }
     }
@@ -1153,6 +1356,11 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     float a[KA];
 
     auto emit = [&](const int s0, const int s1) {
+#if defined(FSMC_DIAG_NOSMEM) || defined(FSMC_DIAG_NOEMIS) || defined(FSMC_DIAG_SAMEROW)
+      if (s0 >= 0) { // garbage posteriors would flood the record buffer
+        return;
+      }
+#endif
       const unsigned idx = atomicAdd(&p.counters[1], 1u);
       float mean = 0.f, mapv = 0.f;
       if constexpr (TRACK) {
@@ -1171,11 +1379,14 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       }
     };
     // LDS-DMA of one stored beta row (K4 x 1 KiB) into the landing zone: asynchronous, no VGPRs
-    auto fetchBeta = [&](const float4* src) {
+    auto fetchBeta = [&](const float4* row) { // row: wave-uniform address of the stored vector
+      const char* const base = uniformPtr(row);
 #pragma unroll
       for (int k4 = 0; k4 < K4; ++k4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_global_load_lds(src + (size_t)k4 * kWave, &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
+        __builtin_amdgcn_global_load_lds(
+            reinterpret_cast<const f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff),
+            &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
 #endif
       }
     };
@@ -1186,22 +1397,77 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       if (!single) {
         // park the carried alpha while the chunk's betas are rebuilt
         if (j > 0) {
-          store_vec<KT, KA>(K, saveA + lane, a);
+          store_vec<KT, KA>(K, saveA, laneOff, a);
         }
-        {
+        auto storeRow = [&](const int site, const float (&row)[KA]) {
+          const int rel = site - lo;
+          if (!HALF || (rel & 1) || site == hi - 1) {
+            store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4, laneOff, row);
+          }
+        };
+        if constexpr (kRotate) {
+          // same rotation as pass B: (w, bsum) is the pending un-normalised row; a checkpoint is loaded as a row with
+          // sum 1.0f (w * (1.0f / 1.0f) is an exact copy) and belongs to the next chunk (not stored here)
+          float b[KA];
+          float bsum = 0.f;
+          int pos;
+          if (hi == to) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              w[k] = (!kGhost<KT> || k < p.K) ? 1.0f : 0.f;
+              bsum = bsum + w[k];
+            }
+            pos = to - 2;
+          } else {
+            load_vec<KT, KA>(K, ckpt + (size_t)(j + 1) * vecF4, laneOff, w);
+            bsum = 1.0f;
+            pos = hi - 1;
+          }
+          EmisRegs ev;
+          int rowNext = 0;
+          if (pos >= lo) {
+            ev = prefetchEmis(pos + 1);
+            rowNext = tStepRow[pos + 1];
+          }
+          for (; pos >= lo; --pos) {
+            const int q = pos + 1;
+            commitEmis(q, ev);
+            const int row = rowNext;
+            if (pos - 1 >= lo) {
+              ev = prefetchEmis(q - 1);
+              rowNext = tStepRow[q - 1];
+            }
+            const int c = obsClass(q);
+            const float4* e = &emisLds[q & 1][c * E4];
+            const cfloat_p rs = rowSetOf<KT>(tabs, row);
+            BetaOps<KT> ops;
+            beta_issue_pk<KT>(ops, rs, e);
+            FSMC_END(cycW, 0);
+            scale_pk<KT, KA>(b, w, bsum); // beta of site q, final
+            if (q < hi) {
+              storeRow(q, b);
+            }
+            FSMC_END(cycW, 1);
+            bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, e, tabs.ghostMask, cycW);
+          }
+          scale_pk<KT, KA>(b, w, bsum);
+          if (pos + 1 < hi) {
+            storeRow(pos + 1, b);
+          }
+        } else {
           float b[KA];
           int pos;
           if (hi == to) {
-            beta_init<KT, KA>(K, b);
+            beta_init<KT, KA>(K, p.K, b);
             if constexpr (SEQ) {
               if (to - 1 > from) {
                 betaGapStep(b, to - 1, prefetchEmis(to - 1));
               }
             }
-            store_vec<KT, KA>(K, chunkbuf + slotOf(to - 1 - lo) * vecF4 + lane, b);
+            store_vec<KT, KA>(K, chunkbuf + slotOf(to - 1 - lo) * vecF4, laneOff, b);
             pos = to - 2;
           } else {
-            load_vec<KT, KA>(K, ckpt + (size_t)(j + 1) * vecF4 + lane, b);
+            load_vec<KT, KA>(K, ckpt + (size_t)(j + 1) * vecF4, laneOff, b);
             pos = hi - 1;
             if constexpr (SEQ) {
               commitEmis(hi, prefetchEmis(hi)); // the checkpoint is the stored vector of site hi: its rows next
@@ -1210,7 +1476,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           if constexpr (SEQ) {
             for (; pos >= lo; --pos) {
               betaSeqStep(b, pos);
-              store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
+              store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4, laneOff, b);
             }
           } else {
             EmisRegs ev;
@@ -1219,37 +1485,31 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               ev = prefetchEmis(pos + 1);
               rowNext = tStepRow[pos + 1];
             }
-            BetaHead head;
-            bool primed = false;
             for (; pos >= lo; --pos) {
               const int q = pos + 1;
               commitEmis(q, ev);
               const int row = rowNext;
-              rowNext = -1;
               if (pos - 1 >= lo) {
                 ev = prefetchEmis(q - 1);
                 rowNext = tStepRow[q - 1];
               }
               const int c = obsClass(q);
-              beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW, head, primed, rowNext);
-              primed = rowNext >= 0;
-              const int rel = pos - lo;
-              if (!HALF || (rel & 1) || pos == hi - 1) {
-                store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4 + lane, b);
-              }
+              beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+              storeRow(pos, b);
             }
           }
         }
         if (j > 0) {
-          load_vec<KT, KA>(K, saveA + lane, a);
+          load_vec<KT, KA>(K, saveA, laneOff, a);
         }
       }
 
+      FSMC_END(cycW, 13);
       FSMC_STAMP(cycR);
       // the wave's own stores of this chunk's betas must have landed before the DMA reads them back
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
-      fetchBeta(chunkbuf + lane);
+      waitVm0();
+      fetchBeta(chunkbuf);
       EmisRegs ev = prefetchEmis(lo);
       EmisRegs ev2 = ev; // HALF: the rows of the second site of a pair of sites
       if constexpr (SEQ) {
@@ -1260,9 +1520,17 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           ev2 = prefetchEmis(lo + 1);
         }
       }
+      // table rows of the steps into the next sites, requested two sites ahead (a scalar load waited for at its use
+      // costs the wave a round trip to L2 at every site)
+      const int lastSite = p.S - 1;
+      int rowA0 = tStepRow[lo];                                  // row of the step into site pos
+      int rowA1 = tStepRow[lo + 1 < lastSite ? lo + 1 : lastSite]; // ... into site pos + 1
       for (int pos = lo; pos < hi; ++pos) {
         // HALF: this site's beta row was not stored -- it is recomputed below from the row of site pos+1
         const bool rec = HALF && ((pos - lo) & 1) == 0 && pos + 1 < hi;
+        const int rowPos = rowA0, rowPos1 = rowA1;
+        rowA0 = rowA1;
+        rowA1 = tStepRow[pos + 2 < lastSite ? pos + 2 : lastSite];
 
         if constexpr (SEQ) {
           if (pos < to - 1) {
@@ -1291,11 +1559,11 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
         const int c = obsClass(pos);
         const float4* e = &emisLds[pos & 1][c * E4];
+        FSMC_END(cycW, 4);
         if (pos == from) {
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
-          const int row = tStepRow[pos];
-          alpha_step<KT, KA>(K, a, w, tabs, row, e, cycW);
+          alpha_step<KT, KA>(K, a, w, tabs, rowPos, e, cycW);
         }
         if constexpr (SEQ) {
           // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step
@@ -1309,26 +1577,41 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
 
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
-        FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
+        waitVm0();
         __builtin_amdgcn_wave_barrier();
+        FSMC_END(cycW, 8);
         float sumq = 0.f;
         if (rec) {
           // the landing zone holds beta of site pos+1: one beta step back gives this site's row (the same
           // operations, on the same bits, as the pass that stored its neighbours), combined from registers
           float b[KA];
-#pragma unroll
-          for (int k4 = 0; k4 < K4; ++k4) {
-            const float4 o = betaLds[k4 * kWave + lane];
-            b[4 * k4] = o.x;
-            if (4 * k4 + 1 < K) b[4 * k4 + 1] = o.y;
-            if (4 * k4 + 2 < K) b[4 * k4 + 2] = o.z;
-            if (4 * k4 + 3 < K) b[4 * k4 + 3] = o.w;
-          }
           const int q = pos + 1;
           const int cq1 = obsClass(q);
-          const int rowq = tStepRow[q];
-          BetaHead head;
-          beta_step<KT, KA>(K, b, w, tabs, rowq, &emisLds[q & 1][cq1 * E4], cycW, head);
+          const int rowq = rowPos1;
+          const float4* eq = &emisLds[q & 1][cq1 * E4];
+          auto readLanded = [&]() {
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) {
+              const float4 o = betaLds[k4 * kWave + lane];
+              b[4 * k4] = o.x;
+              if (4 * k4 + 1 < K) b[4 * k4 + 1] = o.y;
+              if (4 * k4 + 2 < K) b[4 * k4 + 2] = o.z;
+              if (4 * k4 + 3 < K) b[4 * k4 + 3] = o.w;
+            }
+          };
+          if constexpr (KT > 0 && kPacked) {
+            const cfloat_p rs = rowSetOf<KT>(tabs, rowq);
+            BetaOps<KT> ops;
+            beta_issue_pk<KT>(ops, rs, eq); // in flight while the landed row moves from LDS to registers
+            readLanded();
+            FSMC_END(cycW, 9);
+            const float bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, eq, tabs.ghostMask, cycW);
+            scale_pk<KT, KA>(b, w, bsum);
+          } else {
+            readLanded();
+            beta_step<KT, KA>(K, b, w, tabs, rowq, eq, cycW);
+          }
+          FSMC_END(cycW, 9);
 #pragma unroll
           for (int k = 0; k < K; k += 2) {
             if (KT > 0 && k + 1 < K) { // products two states at a time, the sum in state order
@@ -1395,12 +1678,14 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           }
         }
         const float cq = 1.0f / sumq;
+        FSMC_END(cycW, 10);
         // every read of the landing zone has returned: request the next site's beta row
-        FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
+        waitLgkm0();
         if (MODE != kModeSums && !rec && pos + 1 < hi) {
-          fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4 + lane);
+          fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4);
         }
 
+        FSMC_END(cycW, 11);
         if (MODE == kModePerPair) {
           // HMM::writePerPairOutput (HMM.cpp:1378-1409): mean = sum_k post*E[t_k] (k ascending from 0.f),
           // MAP = first strictly larger posterior
@@ -1464,10 +1749,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
+          waitLgkm0();
           __builtin_amdgcn_wave_barrier();
           if (pos + 1 < hi) {
-            fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4 + lane);
+            fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4);
           }
         }
 
@@ -1484,25 +1769,23 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             // posterior of the states the scan needs
             // (the states beyond the scan's only feed the per-state sums of open segments: scaled there, by the
             //  lanes that are inside a segment)
+            // Sum over the states below the threshold, k ascending from 0.f (HMM.cpp:1207-1224).  The loop leaves at
+            // the first block of four states beyond the threshold -- one taken branch per site; a guard around every
+            // block was seventeen of them (a taken branch costs this in-order wave ~100 cycles: the scan was 14 % of
+            // the kernel).  Fully unrolled, so the register arrays stay statically indexed.  Inside the last block
+            // the states beyond the threshold add +0.f, which leaves the (non-negative) sum unchanged.
             const unsigned nPost = p.stateThr;
-            // (guards instead of early exits: a data-dependent trip count would turn the register
-            //  arrays into dynamically indexed scratch memory)
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) {
-              if ((unsigned)(4 * k4) < nPost) {
-                w[4 * k4] = w[4 * k4] * cq;
-                if (4 * k4 + 1 < K) w[4 * k4 + 1] = w[4 * k4 + 1] * cq;
-                if (4 * k4 + 2 < K) w[4 * k4 + 2] = w[4 * k4 + 2] * cq;
-                if (4 * k4 + 3 < K) w[4 * k4 + 3] = w[4 * k4 + 3] * cq;
-              }
-            }
             float s = 0.f;
 #pragma unroll
             for (int k4 = 0; k4 < K4; ++k4) {
-              if ((unsigned)(4 * k4) < p.stateThr) {
+              if ((unsigned)(4 * k4) >= nPost) {
+                break;
+              }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  if (4 * k4 + i < K && (unsigned)(4 * k4 + i) < p.stateThr) s = s + w[4 * k4 + i];
+              for (int i = 0; i < 4; ++i) {
+                if (4 * k4 + i < K) {
+                  w[4 * k4 + i] = w[4 * k4 + i] * cq;
+                  s = s + ((unsigned)(4 * k4 + i) < nPost ? w[4 * k4 + i] : 0.f);
                 }
               }
             }
@@ -1516,20 +1799,38 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               // per-state posterior sums of the open segment (sum_posterior_per_state, HMM.cpp:1212-1229): kept
               // in the wave's workspace, touched only by the lanes that are inside a segment at this site
               if (level != 4) {
+                // four blocks (sixteen states) per round trip: the loads of a round go out together, lanes that
+                // open a segment at this site start from zero instead of what they loaded
+                constexpr int kG = 4;
+                char* const spsBase = const_cast<char*>(uniformPtr(saveS)); // scalar base + lane offset + immediate
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) {
-                  if ((unsigned)(4 * k4) < p.ageThr) {
-                    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!opening) {
-                      sv = spsMem[(size_t)k4 * kWave];
+                for (int g4 = 0; g4 < K4; g4 += kG) {
+                  if ((unsigned)(4 * g4) >= p.ageThr) {
+                    break;
+                  }
+                  float4 sv[kG];
+#pragma unroll
+                  for (int j = 0; j < kG; ++j) {
+                    if (g4 + j < K4) {
+                      sv[j] = *reinterpret_cast<const float4*>(spsBase + (size_t)(g4 + j) * (kWave * sizeof(float4)) + laneOff);
                     }
-                    // blocks the scan already normalised are taken as they are (x * 1.0f is exact)
-                    const float sc = ((unsigned)(4 * k4) < nPost) ? 1.0f : cq;
-                    sv.x = sv.x + w[4 * k4] * sc;
-                    if (4 * k4 + 1 < K) sv.y = sv.y + w[4 * k4 + 1] * sc;
-                    if (4 * k4 + 2 < K) sv.z = sv.z + w[4 * k4 + 2] * sc;
-                    if (4 * k4 + 3 < K) sv.w = sv.w + w[4 * k4 + 3] * sc;
-                    spsMem[(size_t)k4 * kWave] = sv;
+                  }
+#pragma unroll
+                  for (int j = 0; j < kG; ++j) {
+                    const int k4 = g4 + j;
+                    if (k4 < K4) {
+                      if (opening) {
+                        sv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                      }
+                      // blocks the scan already normalised are taken as they are (x * 1.0f is exact); states at or
+                      // beyond the age threshold are never read back (segment_ages stops there)
+                      const float sc = ((unsigned)(4 * k4) < nPost) ? 1.0f : cq;
+                      sv[j].x = sv[j].x + w[4 * k4] * sc;
+                      if (4 * k4 + 1 < K) sv[j].y = sv[j].y + w[4 * k4 + 1] * sc;
+                      if (4 * k4 + 2 < K) sv[j].z = sv[j].z + w[4 * k4 + 2] * sc;
+                      if (4 * k4 + 3 < K) sv[j].w = sv[j].w + w[4 * k4 + 3] * sc;
+                      *reinterpret_cast<float4*>(spsBase + (size_t)k4 * (kWave * sizeof(float4)) + laneOff) = sv[j];
+                    }
                   }
                 }
               }
@@ -1546,16 +1847,25 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
           }
         }
+        FSMC_END(cycW, 12);
       }
       FSMC_STAMP(cycA);
     }
+#if defined(FSMC_REGION_STAMPS)
+    if (lane == 0 && p.phaseCycles) {
+#pragma unroll
+      for (int r = 0; r < kDiagRegions; ++r) {
+        atomicAdd(&p.phaseCycles[8 + r], (unsigned long long)cycW.acc[r]);
+      }
+    }
+#endif
 #if defined(FSMC_PHASE_STAMPS)
     if (lane == 0 && p.phaseCycles) {
       atomicAdd(&p.phaseCycles[0], (unsigned long long)cycB);
       atomicAdd(&p.phaseCycles[1], (unsigned long long)cycR);
       atomicAdd(&p.phaseCycles[2], (unsigned long long)cycA);
       atomicAdd(&p.phaseCycles[3], 1ull);
-      atomicAdd(&p.phaseCycles[4], (unsigned long long)cycW);
+      atomicAdd(&p.phaseCycles[4], (unsigned long long)cycW.waitCycles);
     }
 #endif
   }

@@ -382,6 +382,7 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
   float4* const saveA = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
   float4* const saveS = saveA + vecF4;
   float4* const spsMem = saveS + lane;
+  const unsigned laneOff = (unsigned)lane * (unsigned)sizeof(float4); // this lane's byte offset inside a 1-KiB row
   const int C = p.chunk;
   const float4* const rowSets4 = reinterpret_cast<const float4*>(p.rowSets);
   const float4* const cR4 = reinterpret_cast<const float4*>(p.cR);
@@ -433,11 +434,14 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
     FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   };
-  auto fetchBeta = [&](const float4* src) {
+  auto fetchBeta = [&](const float4* row) { // row: wave-uniform address of the stored vector (see store_vec)
+    const char* const base = uniformPtr(row);
 #pragma unroll
     for (int k4 = 0; k4 < (KQ / 4); ++k4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      __builtin_amdgcn_global_load_lds(src + (size_t)k4 * kWave, &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
+      __builtin_amdgcn_global_load_lds(
+          reinterpret_cast<const f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff), &betaLds[k4 * kWave],
+          16, 0, 2 /* nt */);
 #endif
     }
   };
@@ -525,13 +529,13 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
       auto afterBeta = [&](const int pos) {
         if (single) {
           if (pos < aEnd) {
-            store_vec<KQ, KQ>(KQ, chunkbuf + (size_t)(pos - from) * vecF4 + lane, b);
+            store_vec<KQ, KQ>(KQ, chunkbuf + (size_t)(pos - from) * vecF4, laneOff, b);
           }
         } else {
           const int rel = pos - from;
           if (rel > 0 && pos <= aEnd && (rel % C == 0 || pos == aEnd)) {
             const int j = (pos == aEnd) ? nChunks : rel / C;
-            store_vec<KQ, KQ>(KQ, ckpt + (size_t)j * vecF4 + lane, b);
+            store_vec<KQ, KQ>(KQ, ckpt + (size_t)j * vecF4, laneOff, b);
           }
         }
       };
@@ -584,17 +588,17 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
       const int hi = (lo + C < aEnd) ? lo + C : aEnd;
       if (!single) {
         if (jc > 0) {
-          store_vec<KQ, KQ>(KQ, saveA + lane, a);
+          store_vec<KQ, KQ>(KQ, saveA, laneOff, a);
         }
         {
           float b[KQ];
           int pos;
           if (hi == to) {
             betaInit(b);
-            store_vec<KQ, KQ>(KQ, chunkbuf + (size_t)(to - 1 - lo) * vecF4 + lane, b);
+            store_vec<KQ, KQ>(KQ, chunkbuf + (size_t)(to - 1 - lo) * vecF4, laneOff, b);
             pos = to - 2;
           } else {
-            load_vec<KQ, KQ>(KQ, ckpt + (size_t)(jc + 1) * vecF4 + lane, b);
+            load_vec<KQ, KQ>(KQ, ckpt + (size_t)(jc + 1) * vecF4, laneOff, b);
             pos = hi - 1;
           }
           if (pos >= lo) {
@@ -617,11 +621,11 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
             }
             betaStep(b, q);
             ldsReadsDone();
-            store_vec<KQ, KQ>(KQ, chunkbuf + (size_t)(pos - lo) * vecF4 + lane, b);
+            store_vec<KQ, KQ>(KQ, chunkbuf + (size_t)(pos - lo) * vecF4, laneOff, b);
           }
         }
         if (jc > 0) {
-          load_vec<KQ, KQ>(KQ, saveA + lane, a);
+          load_vec<KQ, KQ>(KQ, saveA, laneOff, a);
         }
       }
 
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       landed();
       ldsReadsDone();
-      fetchBeta(chunkbuf + lane);
+      fetchBeta(chunkbuf);
       stageEmis(lo);
       if (lo > from) {
         stageRows(lo, true);
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
         // every LDS read of this site's rows and of the landing zone has returned: request the next site's
         ldsReadsDone();
         if (pos + 1 < hi) {
-          fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4 + lane);
+          fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
           stageEmis(pos + 1);
           stageRows(pos + 1, true);
         }

@@ -496,6 +496,16 @@ std::vector<bool> Data::genotypeVector(size_t hapRow) const
   return v;
 }
 
+std::vector<Individual> Data::individuals() const
+{
+  std::vector<Individual> out(numIndividuals(), Individual(sites));
+  for (size_t i = 0; i < out.size(); ++i) {
+    out[i].genotype1 = genotypeVector(2 * i);
+    out[i].genotype2 = genotypeVector(2 * i + 1);
+  }
+  return out;
+}
+
 std::vector<std::vector<int>> Data::calculateUndistinguishedCounts(const int numCsfsSamples) const
 {
   // Data.cpp:567-599

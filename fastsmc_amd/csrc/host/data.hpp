@@ -15,6 +15,25 @@
 namespace fsmc_host
 {
 
+// Individual.hpp:25-40: the two haplotypes of one diploid sample as bit vectors.  The decode path keeps genotypes
+// packed (Data::bits); this is the reference's view of them for API users (Data::individuals()).
+class Individual
+{
+public:
+  std::vector<bool> genotype1;
+  std::vector<bool> genotype2;
+
+  explicit Individual(int numOfSites = 0) : genotype1(static_cast<size_t>(numOfSites)), genotype2(static_cast<size_t>(numOfSites)) {}
+  void setGenotype(int_least8_t hap, int pos, bool val) // Individual.cpp:25-32: hap 1 -> genotype1, anything else -> genotype2
+  {
+    if (hap == 1) {
+      genotype1[static_cast<size_t>(pos)] = val;
+    } else {
+      genotype2[static_cast<size_t>(pos)] = val;
+    }
+  }
+};
+
 class Data
 {
 public:
@@ -38,6 +57,8 @@ public:
     return (bits[hapRow * wordsPerHap + (site >> 6)] >> (site & 63)) & 1ull;
   }
   std::vector<bool> genotypeVector(size_t hapRow) const;
+  // the reference's Data::individuals (Data.hpp:36), unpacked on demand from the bit matrix
+  std::vector<Individual> individuals() const;
   size_t numIndividuals() const { return FamIDList.size(); }
   size_t numHapRows() const { return 2 * FamIDList.size(); }
   // number of local haplotype row r in the whole file: 2 * (sample line of its individual) + r % 2

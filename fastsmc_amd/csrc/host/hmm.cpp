@@ -501,6 +501,18 @@ PairObservations HMM::makePairObs(int_least8_t iHap, unsigned ind1, int_least8_t
   return ret;
 }
 
+std::vector<PairObservations> HMM::getBatchBuffer() const
+{
+  std::vector<PairObservations> out;
+  for (size_t i = mBatchBegin; i < mPairs.size(); ++i) {
+    const auto [indA, hapA] = hapToDipId(mPairs[i].hap_a);
+    const auto [indB, hapB] = hapToDipId(mPairs[i].hap_b);
+    out.push_back(makePairObs(static_cast<int_least8_t>(hapA), static_cast<unsigned>(indA),
+                              static_cast<int_least8_t>(hapB), static_cast<unsigned>(indB)));
+  }
+  return out;
+}
+
 void HMM::queuePair(unsigned hapRowA, unsigned hapRowB)
 {
   if (hapRowA >= mData.numHapRows() || hapRowB >= mData.numHapRows()) {
@@ -936,6 +948,34 @@ std::vector<std::vector<float>> HMM::decode(const PairObservations& obs, unsigne
     }
   }
   return posterior;
+}
+
+std::pair<std::vector<float>, std::vector<float>> HMM::decodeSummarize(const PairObservations& obs)
+{
+  // HMM.cpp:1498-1517: mean[j] = sum_i posterior[i][j] * expectedTimes[i] (i ascending from 0.f), MAP[j] =
+  // expectedTimes of the first state with a strictly larger posterior -- the per-pair consumer of the decode
+  // kernel evaluates exactly these two in this order (fsmc_decode_per_pair with expectedTimes as the weights).
+  if (mParams.doPosteriorSums) {
+    (void)decode(obs); // the reference's decodeSummarize goes through decode(), which adds to sumOverPairs
+  }
+  if (!mGroups.empty() || !mPairs.empty()) {
+    throw std::runtime_error("decodeSummarize: pairs are queued; call finishDecoding() first");
+  }
+  ensureEngine();
+  const size_t S = static_cast<size_t>(mData.sites);
+  const fsmc_pair pr{static_cast<uint32_t>(dipToHapId(obs.iInd, static_cast<unsigned long>(obs.iHap))),
+                     static_cast<uint32_t>(dipToHapId(obs.jInd, static_cast<unsigned long>(obs.jHap)))};
+  const fsmc_group g{0, 1, 0, static_cast<uint32_t>(S), 0, static_cast<uint32_t>(S)};
+  check(mCtx, fsmc_worklist_upload(mCtx, &pr, 1, &g, 1), "fsmc_worklist_upload");
+  std::vector<float> mean(S);
+  std::vector<int32_t> arg(S);
+  check(mCtx, fsmc_decode_per_pair(mCtx, mModel, mDq.expectedTimes.data(), mean.data(), arg.data()),
+        "fsmc_decode_per_pair");
+  std::vector<float> map(S);
+  for (size_t s = 0; s < S; ++s) {
+    map[s] = mDq.expectedTimes[static_cast<size_t>(arg[s])];
+  }
+  return {map, mean};
 }
 
 } // namespace fsmc_host

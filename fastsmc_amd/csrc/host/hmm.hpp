@@ -97,15 +97,30 @@ public:
   // posterior of one pair, [states][to-from] (HMM::decode, HMM.cpp:1464-1508 -- here via the batched GPU path)
   std::vector<std::vector<float>> decode(const PairObservations& obs);
   std::vector<std::vector<float>> decode(const PairObservations& obs, unsigned from, unsigned to);
+  // (MAP, posterior mean) of one pair, one value per site, both in units of expectedTimes (HMM.cpp:1498-1517)
+  std::pair<std::vector<float>, std::vector<float>> decodeSummarize(const PairObservations& obs);
 
-  DecodingReturnValues& getDecodingReturnValues() { return mReturn; }
-  DecodePairsReturnStruct& getDecodePairsReturnStruct() { return mPairsReturn; }
+  // The reference decodes a batch the moment it is full (addToBatch, HMM.cpp:555-590); here full batches wait in the
+  // work list until a flush (many batches per launch), so the getters of results decode what is waiting first.
+  DecodingReturnValues& getDecodingReturnValues()
+  {
+    flush();
+    return mReturn;
+  }
+  DecodePairsReturnStruct& getDecodePairsReturnStruct()
+  {
+    flush();
+    return mPairsReturn;
+  }
   const DecodingQuantities& getDecodingQuantities() const { return mDq; }
   const Data& getData() const { return mData; }
   const PreparedModel& getPreparedModel() const { return mPrep; }
   const DecodingParams& getParams() const { return mParams; }
-  // number of pairs waiting for the next flush (the reference's batch buffer holds at most batchSize)
+  // pairs queued since the last flush, full batches included
   size_t getQueuedPairs() const { return mPairs.size(); }
+  // HMM::getBatchBuffer (HMM.hpp:215): the observations of the OPEN batch -- empty again whenever a batch fills up
+  // (TESTS/test_HMM.cpp:49-79)
+  std::vector<PairObservations> getBatchBuffer() const;
 
   void setStorePerPairPosteriorMean(bool v) { mStoreMean = v; }
   void setStorePerPairMap(bool v) { mStoreMap = v; }

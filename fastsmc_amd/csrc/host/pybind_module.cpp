@@ -9,6 +9,7 @@
 #include "binary_reader.hpp"
 #include "drivers.hpp"
 #include "hashing.hpp"
+#include "util.hpp"
 
 namespace py = pybind11;
 using namespace py::literals;
@@ -325,10 +326,18 @@ PYBIND11_MODULE(_pyasmc, m)
       .def_readwrite("windowSize", &Data::windowSize)
       .def_readwrite("w_i", &Data::w_i)
       .def_readwrite("w_j", &Data::w_j)
+      .def_property_readonly("individuals", &Data::individuals,
+                             "list of Individual (genotype1 / genotype2), unpacked from the bit matrix (Data.hpp:36)")
       .def("genotype", &Data::genotypeVector, "hapRow"_a, "folded genotype of haplotype row 2*ind + (hap-1)")
       .def("packed_bits", [](const Data& d) {
         return toArray<uint64_t>(d.bits, {static_cast<py::ssize_t>(d.numHapRows()), static_cast<py::ssize_t>(d.wordsPerHap)});
       });
+
+  py::class_<Individual>(m, "Individual")
+      .def(py::init<int>(), "numOfSites"_a = 0)
+      .def("setGenotype", &Individual::setGenotype, "hap"_a, "pos"_a, "val"_a)
+      .def_readwrite("genotype1", &Individual::genotype1)
+      .def_readwrite("genotype2", &Individual::genotype2);
 
   py::class_<HMM>(m, "HMM")
       .def(py::init([](const Data& d, const DecodingParams& p, int scalingSkip) { return new HMM(d, p, scalingSkip); }),
@@ -350,8 +359,10 @@ PYBIND11_MODULE(_pyasmc, m)
       .def("setShard", &HMM::setShard, "rank"_a, "world"_a,
            "decode only shard `rank` of `world` (contiguous whole batches) and write <file>.part<rank>of<world>")
       .def("ibdFileName", &HMM::ibdFileName, "jobs"_a, "jobInd"_a)
-      .def("getBatchBuffer", [](const HMM& h) { return std::vector<int>(h.getQueuedPairs(), 0); },
-           "one entry per queued pair (the reference returns its vector of queued PairObservations)")
+      .def("decodeSummarize", &HMM::decodeSummarize, "(MAP, posterior mean) per site of one pair (HMM.cpp:1498)")
+      .def("getBatchBuffer", &HMM::getBatchBuffer,
+           "PairObservations of the open batch; empty whenever a batch has just filled up (HMM.hpp:215)")
+      .def("getQueuedPairs", &HMM::getQueuedPairs, "pairs waiting for the next launch, full batches included")
       .def("finishDecoding", &HMM::finishDecoding)
       .def("finishFromHashing", &HMM::finishFromHashing)
       .def("closeIBDFile", &HMM::closeIBDFile)
@@ -455,6 +466,26 @@ PYBIND11_MODULE(_pyasmc, m)
           return out;
         },
         "data"_a, "params"_a, "candidate (hapA, hapB, fromSite, toSite) list of the identification step");
+  // StringUtils::stof / stod (StringUtils.cpp:36-44): std::stold narrowed; std::out_of_range -> OverflowError is not a
+  // pybind default, so both standard exceptions surface as ValueError subclasses with the C++ type in the message
+  m.def("stof", [](const std::string& s) {
+    try {
+      return refStof(s);
+    } catch (const std::out_of_range& e) {
+      throw py::value_error(std::string("std::out_of_range: ") + e.what());
+    } catch (const std::invalid_argument& e) {
+      throw py::value_error(std::string("std::invalid_argument: ") + e.what());
+    }
+  });
+  m.def("stod", [](const std::string& s) {
+    try {
+      return refStod(s);
+    } catch (const std::out_of_range& e) {
+      throw py::value_error(std::string("std::out_of_range: ") + e.what());
+    } catch (const std::invalid_argument& e) {
+      throw py::value_error(std::string("std::invalid_argument: ") + e.what());
+    }
+  });
   m.def("roundMorgans", &roundMorgans, "value"_a, "precision"_a, "min"_a);
   m.def("roundPhysical", &roundPhysical, "value"_a, "precision"_a);
   m.def("getFromPosition", &getFromPosition, "geneticPositions"_a, "from"_a, "cmDist"_a = 0.5f);

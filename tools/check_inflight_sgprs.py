@@ -20,9 +20,22 @@ def sgprs(tok: str):
 
 
 def all_sgprs(line: str):
+    """SGPRs an instruction names.  A packed VALU instruction whose op_sel_hi bit for an SGPR-pair source is 0 (and
+    whose op_sel bit is not set) reads the pair's LOW register for both halves: the high register is not touched."""
     out = set()
+    low_only = set()
+    m = re.search(r"op_sel_hi:\[([01,]+)\]", line)
+    if line.startswith("v_pk_") and m and "op_sel:" not in line:
+        hi = [int(x) for x in m.group(1).split(",")]
+        ops = [t.strip() for t in line.split(None, 1)[1].split("op_sel_hi")[0].split(",")]
+        for idx, tok in enumerate(ops[1:]):  # sources
+            if idx < len(hi) and hi[idx] == 0 and re.fullmatch(r"s\[(\d+):(\d+)\]", tok):
+                low_only.add(tok)
     for t in re.findall(r"s\[\d+:\d+\]|\bs\d+\b", line):
-        out |= sgprs(t)
+        regs = sgprs(t)
+        if t in low_only:
+            regs = {min(regs)}
+        out |= regs
     return out
 
 

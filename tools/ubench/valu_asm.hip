@@ -35,6 +35,18 @@ template <int MODE> __global__ void k(float* out, int iters, float s0)
         asm volatile("v_readlane_b32 %0, %4, 3\n v_readlane_b32 %1, %4, 5\n v_readlane_b32 %2, %4, 7\n v_readlane_b32 %3, %4, 9\n"
                      "v_readlane_b32 %0, %4, 13\n v_readlane_b32 %1, %4, 15\n v_readlane_b32 %2, %4, 17\n v_readlane_b32 %3, %4, 19"
                      : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3) : "v"(a0));
+      } else if (MODE == 6) { // packed, both sources VGPR pairs
+        asm volatile("v_pk_mul_f32 %0, %0, %7\n v_pk_mul_f32 %1, %1, %7\n v_pk_mul_f32 %2, %2, %7\n v_pk_mul_f32 %3, %3, %7\n"
+                     "v_pk_mul_f32 %4, %4, %7\n v_pk_mul_f32 %5, %5, %7\n v_pk_mul_f32 %6, %6, %7\n v_pk_mul_f32 %0, %0, %7"
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6) : "v"(p7));
+      } else if (MODE == 7) { // the step's mix: three packed instructions and five plain ones, a sequential add chain among them
+        asm volatile("v_pk_mul_f32 %1, %1, %4\n v_add_f32 %0, %0, %6\n v_pk_mul_f32 %2, %2, %4\n v_add_f32 %0, %0, %7\n"
+                     "v_pk_add_f32 %3, %3, %1\n v_add_f32 %0, %0, %6\n v_mul_f32 %0, %5, %0\n v_add_f32 %0, %0, %7"
+                     : "+v"(a0), "+v"(p1), "+v"(p2), "+v"(p3) : "s"(sp), "s"(s0), "v"(a1), "v"(a2));
+      } else if (MODE == 8) { // dependent mul+add recurrence (BU / AU): x = t + r*x
+        asm volatile("v_mul_f32 %0, %2, %0\n v_add_f32 %0, %1, %0\n v_mul_f32 %0, %2, %0\n v_add_f32 %0, %1, %0\n"
+                     "v_mul_f32 %0, %2, %0\n v_add_f32 %0, %1, %0\n v_mul_f32 %0, %2, %0\n v_add_f32 %0, %1, %0"
+                     : "+v"(a0) : "v"(a1), "s"(s0));
       } else if (MODE == 5) {
         asm volatile("v_mul_f32 %0, %2, %0\n v_mul_f32 %1, %2, %1\n v_mul_f32 %0, %2, %0\n v_mul_f32 %1, %2, %1\n"
                      "v_mul_f32 %0, %2, %0\n v_mul_f32 %1, %2, %1\n v_mul_f32 %0, %2, %0\n v_mul_f32 %1, %2, %1"
@@ -71,11 +83,14 @@ template <int MODE> void run(const char* name, int wavesPerSimd)
 
 int main()
 {
-  for (int w : {1, 2}) run<0>("v_mul_f32 independent", w);
-  for (int w : {1, 2}) run<1>("v_mul_f32 dependent chain", w);
-  for (int w : {1, 2}) run<5>("v_mul_f32 two chains interleaved", w);
-  for (int w : {1, 2}) run<2>("v_pk_mul_f32 independent", w);
-  for (int w : {1, 2}) run<3>("v_pk_mul_f32 dependent chain", w);
-  for (int w : {1, 2}) run<4>("v_readlane_b32 independent", w);
+  for (int w : {1, 2, 4}) run<0>("v_mul_f32 independent", w);
+  for (int w : {1, 2, 4}) run<1>("v_mul_f32 dependent chain", w);
+  for (int w : {1, 2, 4}) run<5>("v_mul_f32 two chains interleaved", w);
+  for (int w : {1, 2, 4}) run<2>("v_pk_mul_f32 independent", w);
+  for (int w : {1, 2, 4}) run<3>("v_pk_mul_f32 dependent chain", w);
+  for (int w : {1, 2, 4}) run<4>("v_readlane_b32 independent", w);
+  for (int w : {1, 2, 4}) run<6>("v_pk_mul_f32 VGPR x VGPR indep", w);
+  for (int w : {1, 2, 4}) run<7>("step-like mix (3 pk + 5 plain)", w);
+  for (int w : {1, 2, 4}) run<8>("mul+add recurrence, dependent", w);
   return 0;
 }
