@@ -251,6 +251,26 @@ template <int N> struct EmisBlk { // this lane's emission values of one operand 
     return (i & 2) == 0 ? lo : hi;
   }
 };
+// Two-state products and sums: one packed instruction each, or (-DFSMC_UNPACK, an experiment switch) two plain ones.
+// Same IEEE operations either way.
+__device__ __forceinline__ f32x2 pmul(const f32x2 a, const f32x2 b)
+{
+#if defined(FSMC_UNPACK)
+  const f32x2 r = {a.x * b.x, a.y * b.y};
+  return r;
+#else
+  return a * b;
+#endif
+}
+__device__ __forceinline__ f32x2 padd(const f32x2 a, const f32x2 b)
+{
+#if defined(FSMC_UNPACK)
+  const f32x2 r = {a.x + b.x, a.y + b.y};
+  return r;
+#else
+  return a + b;
+#endif
+}
 // values i, i+1 (i even) of a scalar operand block: an aligned SGPR pair
 template <typename V> __device__ __forceinline__ f32x2 pairOf(const V& v, const int i)
 {
@@ -661,8 +681,8 @@ __device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], Be
         const int k = sb * 8 + i;
         if (k + 1 < K) {
           f32x2 v = {b[k], b[k + 1]};
-          v = v * em.pair(o + i);
-          const f32x2 t = pairOf(u, o + i) * v;
+          v = pmul(v, em.pair(o + i));
+          const f32x2 t = pmul(pairOf(u, o + i), v);
           b[k] = v.x;
           b[k + 1] = v.y;
           T[i] = t.x;
@@ -725,17 +745,17 @@ __device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], Be
       const int k = blk * kKB + i;
       if (k + 1 < K) {
         const f32x2 v = {b[k], b[k + 1]};
-        const f32x2 dv = pairOf(d, i) * v;
-        const f32x2 bv = pairOf(bt, i) * v;
+        const f32x2 dv = pmul(pairOf(d, i), v);
+        const f32x2 bv = pmul(pairOf(bt, i), v);
         f32x2 bl;
         bl.x = BL;
         bl.y = BL + bv.x;
-        f32x2 x = bl + dv;
+        f32x2 x = padd(bl, dv);
         const f32x2 bu = {w[k], w[k + 1]};
-        x = x + bu;
+        x = padd(x, bu);
         if constexpr (GHOST) {
           if (blk == NB - 1) {
-            x = x * pairOf(mk, i);
+            x = pmul(x, pairOf(mk, i));
           }
         }
         w[k] = x.x;
@@ -767,7 +787,7 @@ template <int KT, int KA> __device__ __forceinline__ void scale_pk(float (&v)[KA
   for (int k = 0; k < K; k += 2) {
     if (k + 1 < K) {
       const f32x2 x = {w[k], w[k + 1]};
-      const f32x2 y = x * cc;
+      const f32x2 y = pmul(x, cc);
       v[k] = y.x;
       v[k + 1] = y.y;
     } else {
@@ -857,16 +877,16 @@ __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cf
       const int k = blk * kKBF + i;
       if (k + 1 < K - 1) {
         const f32x2 av = {a[k], a[k + 1]};
-        const f32x2 da = pairOf(d, i) * av;
-        const f32x2 ua = pairOf(u, i) * av;
+        const f32x2 da = pmul(pairOf(d, i), av);
+        const f32x2 ua = pmul(pairOf(u, i), av);
         const f32x2 ac = {w[k], w[k + 1]};
-        const f32x2 bw = pairOf(bt, i) * ac;
+        const f32x2 bw = pmul(pairOf(bt, i), ac);
         f32x2 au;
         au.x = AU;
         au.y = ua.x + c4[i] * AU; // AU of state k+1
-        f32x2 term = au + da;
-        term = term + bw;
-        const f32x2 ov = em.pair(i) * term;
+        f32x2 term = padd(au, da);
+        term = padd(term, bw);
+        const f32x2 ov = pmul(em.pair(i), term);
         w[k] = ov.x;
         w[k + 1] = ov.y;
         sum = sum + ov.x;
@@ -997,17 +1017,26 @@ template <int KT, int KA> __device__ __forceinline__ void beta_init(const int K,
 // per-row 64-bit address vectors.  (Kept as per-lane pointers the compiler hoisted eighteen of them out of the site
 // loops, spilled them, and reloaded each in front of its store behind an s_waitcnt vmcnt(0) -- every row went out
 // as fifteen serialised memory round trips, which was 50 % of the kernel's time.)
-__device__ __forceinline__ const char* uniformPtr(const void* p)
+// (the result is typed as a GLOBAL pointer: rebuilt from integers the address space cannot be inferred, and a
+//  generic pointer makes these flat_* instructions, which count in lgkmcnt as well and complete out of order)
+typedef char __attribute__((address_space(1))) * gchar_p;
+typedef f32x4 __attribute__((address_space(1))) * gf32x4_p;
+__device__ __forceinline__ gchar_p uniformPtr(const void* p)
 {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+  return (gchar_p)(((unsigned long long)hi << 32) | lo);
+}
+// address of float4 group k4 of this lane inside the 1-KiB-per-group row at `base`
+__device__ __forceinline__ gf32x4_p rowSlot(const gchar_p base, const int k4, const unsigned laneOff)
+{
+  return (gf32x4_p)(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff);
 }
 template <int KT, int KA>
 __device__ __forceinline__ void store_vec(const int K, float4* row, const unsigned laneOff, const float (&v)[KA])
 {
-  char* const base = const_cast<char*>(uniformPtr(row));
+  const gchar_p base = uniformPtr(row);
   const int K4 = (K + 3) >> 2;
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) {
@@ -1018,19 +1047,18 @@ __device__ __forceinline__ void store_vec(const int K, float4* row, const unsign
     o.w = (4 * k4 + 3 < K) ? v[4 * k4 + 3] : 0.f;
     // streamed once, read back once: keep it from evicting the model tables out of L2
     const f32x4 ov = {o.x, o.y, o.z, o.w};
-    __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff));
+    __builtin_nontemporal_store(ov, rowSlot(base, k4, laneOff));
   }
 }
 
 template <int KT, int KA>
 __device__ __forceinline__ void load_vec(const int K, const float4* row, const unsigned laneOff, float (&v)[KA])
 {
-  const char* const base = uniformPtr(row);
+  const gchar_p base = uniformPtr(row);
   const int K4 = (K + 3) >> 2;
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) {
-    const f32x4 ov = __builtin_nontemporal_load(
-        reinterpret_cast<const f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff));
+    const f32x4 ov = __builtin_nontemporal_load(rowSlot(base, k4, laneOff));
     const float4 o = make_float4(ov.x, ov.y, ov.z, ov.w);
     v[4 * k4] = o.x;
     if (4 * k4 + 1 < K) v[4 * k4 + 1] = o.y;
@@ -1214,6 +1242,51 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       __builtin_amdgcn_wave_barrier();
     };
 
+    // Array mode: a site's emission rows go straight from global memory into ring slot (q & 1) by LDS-DMA -- no
+    // staging registers, no ds_write (kept in registers from one iteration to the next they were spilled: a wait
+    // for the load's round trip plus a scratch store at every site).  Asynchronous: counts in vmcnt and is visible
+    // to this wave's LDS reads behind a vmcnt wait that covers it.  The slot's previous rows must no longer be read.
+    auto stageEmis = [&](const int q) {
+      const gchar_p src = uniformPtr(p.emis3 + (size_t)q * (NC * E4));
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int idx = lane + i * kWave;
+        if (idx < NC * E4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_global_load_lds((gf32x4_p)(src + (size_t)i * (kWave * sizeof(float4)) + laneOff),
+                                           &emisLds[q & 1][i * kWave], 16, 0, 0);
+#endif
+        }
+      }
+    };
+    // Table row of the step into `site`: the indices of 64 consecutive sites sit in one VGPR (lane = site % 64,
+    // one coalesced load per 64 sites) and are picked with v_readlane.  (As scalar loads, one per site, each was
+    // waited for on the spot -- the register allocator had no SGPR to keep it in flight -- a round trip to L2 per
+    // site in the loop heads.)
+    int rowBlk = -1;
+    int rowVec = 0;
+    auto stepRowOf = [&](const int site) -> int {
+      const int blk = site >> 6;
+      if (blk != rowBlk) {
+        const int idx = blk * kWave + lane;
+        rowVec = p.stepRow[idx < p.S ? idx : p.S - 1];
+        rowBlk = blk;
+      }
+      return __builtin_amdgcn_readlane(rowVec, site & (kWave - 1));
+    };
+    // Wait for the emission rows requested one iteration ago (prefetchEmis) while the beta-row stores issued behind
+    // them may still be in flight: vector memory operations retire in order, so "at most K4 outstanding" means the
+    // older request is done.  Explicit, because the compiler cannot count a conditional store burst and would wait
+    // for vmcnt(0) -- i.e. for the stores to reach HBM -- at every site.
+    auto waitEmisRows = [&](const bool storesBehind) {
+      constexpr unsigned n = (unsigned)K4A; // (only the compile-time-K loops call this)
+      if (storesBehind && n < 64) {
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15u) | ((n >> 4) << 14));
+      } else {
+        waitVm0();
+      }
+    };
+
     float w[KA];
     Diag cycW; // diagnostic builds only: cycles parked in operand waits, cycles per code region
 #if defined(FSMC_REGION_STAMPS)
@@ -1268,17 +1341,20 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       // so the next checkpoint is a countdown (no integer division per site).
       int ckJ = (aEnd < to) ? nChunks : nChunks - 1;
       int ckPos = (aEnd < to) ? aEnd : from + ckJ * C;
-      auto afterBeta = [&](const int pos) {
+      auto afterBeta = [&](const int pos) -> bool { // true if a row went out
         if (single) {
           const int rel = pos - from;
           if (pos < aEnd && (!HALF || (rel & 1) || pos == aEnd - 1)) {
             store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4, laneOff, b);
+            return true;
           }
         } else if (pos == ckPos && ckJ >= 1) {
           store_vec<KT, KA>(K, ckpt + (size_t)ckJ * vecF4, laneOff, b);
           ckJ -= 1;
           ckPos = from + ckJ * C;
+          return true;
         }
+        return false;
       };
       if constexpr (SEQ) {
         if (to - 1 > from) {
@@ -1294,11 +1370,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           afterBeta(pos);
         }
       } else {
-        EmisRegs ev;
-        int rowNext = 0;
         if (to - 2 >= from) {
-          ev = prefetchEmis(to - 1);
-          rowNext = tStepRow[to - 1];
+          stageEmis(to - 1);
         }
         if constexpr (kRotate) {
           // Rotated loop: the operand-free tail of a step (1/sum, the scaling multiply, the row store) runs while
@@ -1310,14 +1383,15 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             w[k] = (!kGhost<KT> || k < p.K) ? 1.0f : 0.f;
             bsum = bsum + w[k];
           }
+          bool stored = false;
           for (int pos = to - 2; pos >= from; --pos) {
             const int q = pos + 1;
-            commitEmis(q, ev);
-            const int row = rowNext;
+            waitEmisRows(stored); // the rows of site q have landed
+            __builtin_amdgcn_wave_barrier();
             if (pos - 1 >= from) {
-              ev = prefetchEmis(q - 1);
-              rowNext = tStepRow[q - 1];
+              stageEmis(q - 1); // into the slot of site q + 1, whose step is over
             }
+            const int row = stepRowOf(q);
             const int c = obsClass(q);
             const float4* e = &emisLds[q & 1][c * E4];
             const cfloat_p rs = rowSetOf<KT>(tabs, row);
@@ -1325,7 +1399,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             beta_issue_pk<KT>(ops, rs, e);
             FSMC_END(cycW, 0);
             scale_pk<KT, KA>(b, w, bsum); // beta of site q, final
-            afterBeta(q);
+            stored = afterBeta(q);
             FSMC_END(cycW, 1);
             bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, e, tabs.ghostMask, cycW);
           }
@@ -1334,12 +1408,12 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         } else {
           for (int pos = to - 2; pos >= from; --pos) {
             const int q = pos + 1;
-            commitEmis(q, ev);
-            const int row = rowNext;
+            waitVm0();
+            __builtin_amdgcn_wave_barrier();
             if (pos - 1 >= from) {
-              ev = prefetchEmis(q - 1);
-              rowNext = tStepRow[q - 1];
+              stageEmis(q - 1);
             }
+            const int row = stepRowOf(q);
             const int c = obsClass(q);
             beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
             afterBeta(pos);
@@ -1380,13 +1454,11 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     };
     // LDS-DMA of one stored beta row (K4 x 1 KiB) into the landing zone: asynchronous, no VGPRs
     auto fetchBeta = [&](const float4* row) { // row: wave-uniform address of the stored vector
-      const char* const base = uniformPtr(row);
+      const gchar_p base = uniformPtr(row);
 #pragma unroll
       for (int k4 = 0; k4 < K4; ++k4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_global_load_lds(
-            reinterpret_cast<const f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff),
-            &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
+        __builtin_amdgcn_global_load_lds(rowSlot(base, k4, laneOff), &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
 #endif
       }
     };
@@ -1399,11 +1471,13 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         if (j > 0) {
           store_vec<KT, KA>(K, saveA, laneOff, a);
         }
-        auto storeRow = [&](const int site, const float (&row)[KA]) {
+        auto storeRow = [&](const int site, const float (&row)[KA]) -> bool { // true if the row went out
           const int rel = site - lo;
           if (!HALF || (rel & 1) || site == hi - 1) {
             store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4, laneOff, row);
+            return true;
           }
+          return false;
         };
         if constexpr (kRotate) {
           // same rotation as pass B: (w, bsum) is the pending un-normalised row; a checkpoint is loaded as a row with
@@ -1423,20 +1497,18 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             bsum = 1.0f;
             pos = hi - 1;
           }
-          EmisRegs ev;
-          int rowNext = 0;
           if (pos >= lo) {
-            ev = prefetchEmis(pos + 1);
-            rowNext = tStepRow[pos + 1];
+            stageEmis(pos + 1);
           }
+          bool stored = false;
           for (; pos >= lo; --pos) {
             const int q = pos + 1;
-            commitEmis(q, ev);
-            const int row = rowNext;
+            waitEmisRows(stored); // the rows of site q have landed
+            __builtin_amdgcn_wave_barrier();
             if (pos - 1 >= lo) {
-              ev = prefetchEmis(q - 1);
-              rowNext = tStepRow[q - 1];
+              stageEmis(q - 1); // into the slot of site q + 1, whose step is over
             }
+            const int row = stepRowOf(q);
             const int c = obsClass(q);
             const float4* e = &emisLds[q & 1][c * E4];
             const cfloat_p rs = rowSetOf<KT>(tabs, row);
@@ -1444,9 +1516,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             beta_issue_pk<KT>(ops, rs, e);
             FSMC_END(cycW, 0);
             scale_pk<KT, KA>(b, w, bsum); // beta of site q, final
-            if (q < hi) {
-              storeRow(q, b);
-            }
+            stored = q < hi && storeRow(q, b);
             FSMC_END(cycW, 1);
             bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, e, tabs.ghostMask, cycW);
           }
@@ -1479,20 +1549,17 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               store_vec<KT, KA>(K, chunkbuf + (size_t)(pos - lo) * vecF4, laneOff, b);
             }
           } else {
-            EmisRegs ev;
-            int rowNext = 0;
             if (pos >= lo) {
-              ev = prefetchEmis(pos + 1);
-              rowNext = tStepRow[pos + 1];
+              stageEmis(pos + 1);
             }
             for (; pos >= lo; --pos) {
               const int q = pos + 1;
-              commitEmis(q, ev);
-              const int row = rowNext;
+              waitVm0();
+              __builtin_amdgcn_wave_barrier();
               if (pos - 1 >= lo) {
-                ev = prefetchEmis(q - 1);
-                rowNext = tStepRow[q - 1];
+                stageEmis(q - 1);
               }
+              const int row = stepRowOf(q);
               const int c = obsClass(q);
               beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
               storeRow(pos, b);
@@ -1510,50 +1577,29 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       waitVm0();
       fetchBeta(chunkbuf);
-      EmisRegs ev = prefetchEmis(lo);
-      EmisRegs ev2 = ev; // HALF: the rows of the second site of a pair of sites
+      EmisRegs ev;
       if constexpr (SEQ) {
+        ev = prefetchEmis(lo);
         commitEmis(lo, ev); // later sites are staged by the half-step of the site before them
-      }
-      if constexpr (HALF) {
+      } else {
+        // Array mode: the ring holds the rows of sites pos and pos + 1; after the combine of site pos its slot is
+        // free and takes the rows of site pos + 2, which the vmcnt(0) wait of site pos + 1 covers.
+        stageEmis(lo);
         if (lo + 1 < hi) {
-          ev2 = prefetchEmis(lo + 1);
+          stageEmis(lo + 1);
         }
       }
       // table rows of the steps into the next sites, requested two sites ahead (a scalar load waited for at its use
       // costs the wave a round trip to L2 at every site)
-      const int lastSite = p.S - 1;
-      int rowA0 = tStepRow[lo];                                  // row of the step into site pos
-      int rowA1 = tStepRow[lo + 1 < lastSite ? lo + 1 : lastSite]; // ... into site pos + 1
+      // every request so far (the first beta row, the first sites' emission rows) has landed: inside the loop the
+      // emission registers are then only ever read behind one of its own vmcnt(0) waits, and the compiler adds none
+      waitVm0();
       for (int pos = lo; pos < hi; ++pos) {
         // HALF: this site's beta row was not stored -- it is recomputed below from the row of site pos+1
         const bool rec = HALF && ((pos - lo) & 1) == 0 && pos + 1 < hi;
-        const int rowPos = rowA0, rowPos1 = rowA1;
-        rowA0 = rowA1;
-        rowA1 = tStepRow[pos + 2 < lastSite ? pos + 2 : lastSite];
 
         if constexpr (SEQ) {
           if (pos < to - 1) {
-            ev = prefetchEmis(pos + 1);
-          }
-        } else if constexpr (HALF) {
-          // sites are taken two at a time: stage the rows of both (the beta step back from pos+1 needs them
-          // before the alpha step into pos+1 does), and request the next two
-          if (((pos - lo) & 1) == 0) {
-            commitEmis(pos, ev);
-            if (rec) {
-              commitEmis(pos + 1, ev2);
-            }
-            if (pos + 2 < hi) {
-              ev = prefetchEmis(pos + 2);
-            }
-            if (pos + 3 < hi) {
-              ev2 = prefetchEmis(pos + 3);
-            }
-          }
-        } else {
-          commitEmis(pos, ev);
-          if (pos + 1 < hi) {
             ev = prefetchEmis(pos + 1);
           }
         }
@@ -1563,7 +1609,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         if (pos == from) {
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
-          alpha_step<KT, KA>(K, a, w, tabs, rowPos, e, cycW);
+          alpha_step<KT, KA>(K, a, w, tabs, stepRowOf(pos), e, cycW);
         }
         if constexpr (SEQ) {
           // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step
@@ -1587,7 +1633,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           float b[KA];
           const int q = pos + 1;
           const int cq1 = obsClass(q);
-          const int rowq = rowPos1;
+          const int rowq = stepRowOf(q);
           const float4* eq = &emisLds[q & 1][cq1 * E4];
           auto readLanded = [&]() {
 #pragma unroll
@@ -1617,7 +1663,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             if (KT > 0 && k + 1 < K) { // products two states at a time, the sum in state order
               const f32x2 av = {a[k], a[k + 1]};
               const f32x2 bv = {b[k], b[k + 1]};
-              const f32x2 q = av * bv;
+              const f32x2 q = pmul(av, bv);
               w[k] = q.x;
               w[k + 1] = q.y;
               sumq = sumq + q.x;
@@ -1656,7 +1702,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               if (KT > 0 && k + 1 < K) {
                 const f32x2 av = {a[k], a[k + 1]};
                 const f32x2 bv = {pick(c0, c1, i), pick(c0, c1, i + 1)};
-                const f32x2 q = av * bv;
+                const f32x2 q = pmul(av, bv);
                 w[k] = q.x;
                 w[k + 1] = q.y;
                 sumq = sumq + q.x;
@@ -1683,6 +1729,11 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         waitLgkm0();
         if (MODE != kModeSums && !rec && pos + 1 < hi) {
           fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4);
+        }
+        if constexpr (!SEQ && MODE != kModeSums) {
+          if (pos + 2 < hi) {
+            stageEmis(pos + 2); // this site's ring slot is free: its alpha step (and beta recompute) are over
+          }
         }
 
         FSMC_END(cycW, 11);
@@ -1713,8 +1764,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           // over pairs in batch order (local fp32 sum from 0.f), then added to the accumulator.  The K x 64 tile
           // is transposed through LDS (row stride 65 floats: conflict-free both ways); lane j then owns state j.
           float* const tile = reinterpret_cast<float*>(betaLds);
-          // a ring slot whose rows are no longer needed: this site's in sequence mode, the other one otherwise
-          unsigned char* const cls = reinterpret_cast<unsigned char*>(&emisLds[(SEQ ? pos : pos + 1) & 1][0]);
+          // this site's ring slot: its rows are no longer needed
+          unsigned char* const cls = reinterpret_cast<unsigned char*>(&emisLds[pos & 1][0]);
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             tile[k * 65 + lane] = w[k] * cq;
@@ -1753,6 +1804,11 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           __builtin_amdgcn_wave_barrier();
           if (pos + 1 < hi) {
             fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4);
+          }
+          if constexpr (!SEQ) {
+            if (pos + 2 < hi) {
+              stageEmis(pos + 2);
+            }
           }
         }
 
@@ -1802,7 +1858,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
                 // four blocks (sixteen states) per round trip: the loads of a round go out together, lanes that
                 // open a segment at this site start from zero instead of what they loaded
                 constexpr int kG = 4;
-                char* const spsBase = const_cast<char*>(uniformPtr(saveS)); // scalar base + lane offset + immediate
+                const gchar_p spsBase = uniformPtr(saveS); // scalar base + lane offset + immediate
 #pragma unroll
                 for (int g4 = 0; g4 < K4; g4 += kG) {
                   if ((unsigned)(4 * g4) >= p.ageThr) {
@@ -1812,7 +1868,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
 #pragma unroll
                   for (int j = 0; j < kG; ++j) {
                     if (g4 + j < K4) {
-                      sv[j] = *reinterpret_cast<const float4*>(spsBase + (size_t)(g4 + j) * (kWave * sizeof(float4)) + laneOff);
+                      const f32x4 t = *rowSlot(spsBase, g4 + j, laneOff);
+                      sv[j] = make_float4(t.x, t.y, t.z, t.w);
                     }
                   }
 #pragma unroll
@@ -1829,7 +1886,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
                       if (4 * k4 + 1 < K) sv[j].y = sv[j].y + w[4 * k4 + 1] * sc;
                       if (4 * k4 + 2 < K) sv[j].z = sv[j].z + w[4 * k4 + 2] * sc;
                       if (4 * k4 + 3 < K) sv[j].w = sv[j].w + w[4 * k4 + 3] * sc;
-                      *reinterpret_cast<float4*>(spsBase + (size_t)k4 * (kWave * sizeof(float4)) + laneOff) = sv[j];
+                      const f32x4 t = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
+                      *rowSlot(spsBase, k4, laneOff) = t;
                     }
                   }
                 }

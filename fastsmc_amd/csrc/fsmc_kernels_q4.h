@@ -435,13 +435,11 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
     __builtin_amdgcn_wave_barrier();
   };
   auto fetchBeta = [&](const float4* row) { // row: wave-uniform address of the stored vector (see store_vec)
-    const char* const base = uniformPtr(row);
+    const gchar_p base = uniformPtr(row);
 #pragma unroll
     for (int k4 = 0; k4 < (KQ / 4); ++k4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      __builtin_amdgcn_global_load_lds(
-          reinterpret_cast<const f32x4*>(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff), &betaLds[k4 * kWave],
-          16, 0, 2 /* nt */);
+      __builtin_amdgcn_global_load_lds(rowSlot(base, k4, laneOff), &betaLds[k4 * kWave], 16, 0, 2 /* nt */);
 #endif
     }
   };

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Static check of the compiled decode kernels: the hand-placed scalar loads (inline asm) return their data some
 hundred cycles after they issue, and the compiler does not know that.  Between such a load and the next
-`s_waitcnt lgkmcnt(0)` no instruction may read or write the load's destination SGPRs (a spill would save garbage;
-a reuse would be overwritten when the load lands -- a clobbered pointer is a GPU memory fault).
+`s_waitcnt lgkmcnt(0)` ON ANY PATH no instruction may read or write the load's destination SGPRs (a spill would save
+garbage; a reuse would be overwritten when the load lands -- a clobbered pointer is a GPU memory fault).
+
+The check is a forward data-flow over the kernel's control-flow graph: the set of in-flight destination registers at
+the top of a basic block is the union over its predecessors; an `s_waitcnt` whose lgkmcnt is 0 empties it.
 Reads /tmp/fsmc_isa.s (tools/isa_stats.py writes it); exits 1 on a violation.  Run by tests/test_isa_hazards.py."""
 import re
 import sys
@@ -39,52 +42,111 @@ def all_sgprs(line: str):
     return out
 
 
+class Block:
+    def __init__(self, name):
+        self.name = name
+        self.ins = []  # (line number, text, inside inline asm)
+        self.succ = []
+        self.falls = True
+
+
+def blocks_of(body: str):
+    blocks = [Block("entry")]
+    by_name = {"entry": blocks[0]}
+    in_asm = False
+    for ln_no, ln in enumerate(body.split("\n")):
+        s = ln.strip()
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            b = Block(m.group(1))
+            blocks.append(b)
+            by_name[b.name] = b
+            continue
+        if not s or s.startswith((";", ".")) or s.endswith(":"):
+            continue
+        blocks[-1].ins.append((ln_no, s, in_asm))
+    for i, b in enumerate(blocks):
+        falls = True
+        for _, s, _ in b.ins:
+            op = s.split()[0]
+            if op == "s_branch":
+                b.succ.append(s.split()[1])
+                falls = False
+            elif op.startswith("s_cbranch"):
+                b.succ.append(s.split()[1])
+            elif op in ("s_endpgm", "s_setpc_b64"):
+                falls = False
+        if falls and i + 1 < len(blocks):
+            b.succ.append(blocks[i + 1].name)
+    return blocks, by_name
+
+
+def transfer(b: Block, inflight: dict, report, name):
+    """Walk a block with the in-flight map {sgpr: line of its load}; returns the map at the block's end."""
+    cur = dict(inflight)
+    bad = 0
+    for ln_no, s, in_asm in b.ins:
+        op = s.split()[0]
+        if op == "s_waitcnt" and "lgkmcnt(0)" in s:
+            cur.clear()
+            continue
+        if op.startswith("s_load_dword") and in_asm:
+            toks = s.split()
+            dst = sgprs(toks[1])
+            addr = sgprs(toks[2])
+            if report and addr & set(cur):
+                print(f"{name}: line {ln_no}: address s{sorted(addr & set(cur))} is the destination of a load in "
+                      f"flight: {s}")
+                bad += 1
+            # (several loads into one register may be in flight at once: the line warm-up does that on purpose)
+            for r in dst:
+                cur.setdefault(r, ln_no)
+            continue
+        if cur:
+            clash = all_sgprs(s) & set(cur)
+            if clash and report:
+                print(f"{name}: line {ln_no}: touches s{sorted(clash)} (loaded at line "
+                      f"{min(cur[r] for r in clash)}) before the wait: {s}")
+                bad += 1
+    return cur, bad
+
+
 def check(path: str) -> int:
     txt = open(path).read()
     parts = re.split(r"\n(_ZN4fsmc\d+decode_kernel\w+):[^\n]*\n", txt)
     bad = 0
     for i in range(1, len(parts), 2):
         name, body = parts[i], parts[i + 1].split(".Lfunc_end")[0]
-        inflight = {}  # sgpr -> line of the load
-        in_asm = False
-        for ln_no, ln in enumerate(body.split("\n")):
-            s = ln.strip()
-            if s.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if s.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if not s or s.startswith((";", ".")) or s.endswith(":"):
-                # a label: control flow may merge here; keep tracking conservatively (straight-line order)
-                continue
-            op = s.split()[0]
-            if op == "s_waitcnt" and "lgkmcnt(0)" in s:
-                inflight.clear()
-                continue
-            if op.startswith("s_load_dword") and in_asm:
-                toks = s.split()
-                dst = sgprs(toks[1])
-                addr = sgprs(toks[2])
-                # the address pair must not be the destination of a load that has not returned
-                if addr & set(inflight):
-                    print(f"{name}: line {ln_no}: address s{sorted(addr & set(inflight))} is the destination of a "
-                          f"load in flight: {s}")
-                    bad += 1
-                clash = dst & set(inflight)
-                if clash:
-                    print(f"{name}: line {ln_no}: load into s{sorted(clash)} while an earlier load to it is in flight: {s}")
-                    bad += 1
-                for r in dst:
-                    inflight[r] = ln_no
-                continue
-            if inflight:
-                used = all_sgprs(s)
-                clash = used & set(inflight)
-                if clash:
-                    print(f"{name}: line {ln_no}: touches s{sorted(clash)} (loaded at line "
-                          f"{min(inflight[r] for r in clash)}) before the wait: {s}")
-                    bad += 1
+        blocks, by_name = blocks_of(body)
+        state_in = {b.name: {} for b in blocks}
+        work = [blocks[0].name]
+        seen = set()
+        while work:
+            bn = work.pop()
+            b = by_name[bn]
+            out, _ = transfer(b, state_in[bn], False, name)
+            for sn in b.succ:
+                if sn not in by_name:
+                    continue
+                merged = dict(state_in[sn])
+                changed = sn not in seen
+                for r, l in out.items():
+                    if r not in merged:
+                        merged[r] = l
+                        changed = True
+                if changed:
+                    state_in[sn] = merged
+                    seen.add(sn)
+                    work.append(sn)
+        for b in blocks:
+            _, n = transfer(b, state_in[b.name], True, name)
+            bad += n
     return bad
 
 
