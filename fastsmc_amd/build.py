@@ -17,6 +17,11 @@ HIPCC_FLAGS = [
     "-Wno-pass-failed",  # the generic (runtime-K) instantiation cannot unroll its k-loops, by design
 ]
 
+# family members of the library (csrc/fsmc_instances.h): one translation unit each, compiled in parallel
+KT_MEMBERS = [0, 16, 32, 48, 64, 69, 80]
+Q4_MEMBERS = [32, 48, 64]
+OBJ_DIR = os.path.join(CSRC, "obj")
+
 
 def _newer(target: str, sources: list[str]) -> bool:
     if not os.path.exists(target):
@@ -25,16 +30,55 @@ def _newer(target: str, sources: list[str]) -> bool:
     return all(os.path.getmtime(s) <= t for s in sources)
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """hipcc cross-compiles the gfx950 code object without a GPU."""
-    srcs = [os.path.join(CSRC, f) for f in ("fsmc_capi.hip", "fsmc_kernels.h")]
+def hip_sources() -> list[str]:
+    """Everything the HIP library is built from: every .hip / .h under csrc/ (not host/) and the public header."""
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     srcs.append(os.path.join(ROOT, "include", "fastsmc_hip.h"))
+    return srcs
+
+
+def hip_source_hash() -> str:
+    """Hash of the HIP library's sources: profiles/*_traffic.json carry it so that a measurement of another build
+    is not reported for this one (bench.py)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for s in hip_sources():
+        h.update(os.path.basename(s).encode())
+        h.update(open(s, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    """hipcc cross-compiles the gfx950 code objects without a GPU: fsmc_capi.hip (host side + kernel selection) and
+    fsmc_inst.hip once per family member, in parallel, linked into one shared library."""
+    srcs = hip_sources()
     if not force and _newer(HIP_LIB, srcs):
         return HIP_LIB
-    cmd = ["hipcc", *HIPCC_FLAGS, "-o", HIP_LIB, os.path.join(CSRC, "fsmc_capi.hip")]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c"]
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    subprocess.run(cmd, check=True, cwd=ROOT)
+        cflags.append("-Rpass-analysis=kernel-resource-usage")
+    units = [("capi", os.path.join(CSRC, "fsmc_capi.hip"), [])]
+    units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"]) for k in KT_MEMBERS]
+    units += [(f"q4_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_Q4={k}"]) for k in Q4_MEMBERS]
+    jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
+    pending = list(units)
+    running: list[tuple[str, subprocess.Popen]] = []
+    objs = []
+    failed = []
+    while pending or running:
+        while pending and len(running) < jobs:
+            name, src, defs = pending.pop(0)
+            obj = os.path.join(OBJ_DIR, name + ".o")
+            objs.append(obj)
+            running.append((name, subprocess.Popen(["hipcc", *cflags, *defs, "-o", obj, src], cwd=ROOT)))
+        name, proc = running.pop(0)
+        if proc.wait() != 0:
+            failed.append(name)
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objs], check=True, cwd=ROOT)
     return HIP_LIB
 
 

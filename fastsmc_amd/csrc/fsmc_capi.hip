@@ -16,10 +16,26 @@
 #include <string>
 #include <vector>
 
-#include "fsmc_kernels.h"
-#include "fsmc_kernels_q4.h"
+#include "fsmc_instances.h"
 
 using namespace fsmc;
+
+namespace fsmc
+{
+// Sum of the per-wave accumulator planes in slot order (fixed order => reproducible fp32 result).
+__global__ void reduce_planes_kernel(const float* __restrict__ planes, float* __restrict__ out, size_t n, int nSlots,
+                                     size_t slotStride)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int sl = 0; sl < nSlots; ++sl) {
+      s = s + planes[(size_t)sl * slotStride + i];
+    }
+    out[i] = s;
+  }
+}
+
+} // namespace fsmc
 
 namespace
 {
@@ -64,6 +80,7 @@ struct fsmc_ctx {
   uint32_t chunkSites = 0; // 0 = automatic
   uint32_t betaStride = 0; // 0 = automatic (2 where the kernel exists), 1 = store every beta row
   int lastStride = 1;
+  int lastMember = 0; // family member of the last launch: KT of the lane-per-pair kernel, -KQ of the q4 kernel
 
   const fsmc_model* ibdModel = nullptr;
   uint32_t ibdFlags = 0;
@@ -158,51 +175,53 @@ std::vector<float> padRows(const float* src, size_t rows, int K, int KP)
 
 using KernelFn = void (*)(const KParams);
 
-template <int MODE, bool TRACK, bool SEQ> KernelFn pickKernel(int K, bool half)
+// Which member of the lane-per-pair family decodes a model (fsmc_instances.h): 69 for the reference's 69-state
+// models, the padded row length for every other model of at most 80 states, 0 (runtime K) beyond.
+int familyMember(const fsmc_model* m)
 {
-  switch (K) {
-  case 69:
-    if constexpr (MODE == kModeIbd && !SEQ) {
-      if (half) {
-        return decode_kernel<69, MODE, TRACK, SEQ, true>;
-      }
-    }
-    return decode_kernel<69, MODE, TRACK, SEQ, false>;
-  default:
-    return decode_kernel<0, MODE, TRACK, SEQ, false>;
+  if (m->K == 69) {
+    return 69;
   }
+  return m->K <= 80 ? m->KP : 0;
 }
 
-// Beta stride 2 (every second beta row stored, the others recomputed in the alpha sweep) exists for the
-// compile-time-K array-mode IBD decode -- the path BASELINE.json's metric is quoted on.
-bool halfAvailable(int mode, const fsmc_model* m);
-
-template <bool SEQ> KernelFn pickKernel(int mode, bool track, int K, bool half)
+template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half)
 {
   switch (mode) {
   case kModeIbd:
-    return track ? pickKernel<kModeIbd, true, SEQ>(K, half) : pickKernel<kModeIbd, false, SEQ>(K, half);
+    if constexpr (halfBuilt(KT)) {
+      if (half && !seq) {
+        return track ? decode_kernel<KT, kModeIbd, true, false, true> : decode_kernel<KT, kModeIbd, false, false, true>;
+      }
+    }
+    if (seq) {
+      return track ? decode_kernel<KT, kModeIbd, true, true, false> : decode_kernel<KT, kModeIbd, false, true, false>;
+    }
+    return track ? decode_kernel<KT, kModeIbd, true, false, false> : decode_kernel<KT, kModeIbd, false, false, false>;
   case kModeDump:
-    return pickKernel<kModeDump, false, SEQ>(K, false);
+    return seq ? decode_kernel<KT, kModeDump, false, true, false> : decode_kernel<KT, kModeDump, false, false, false>;
   case kModePerPair:
-    return pickKernel<kModePerPair, false, SEQ>(K, false);
+    return seq ? decode_kernel<KT, kModePerPair, false, true, false>
+               : decode_kernel<KT, kModePerPair, false, false, false>;
   case kModeSums:
-    return pickKernel<kModeSums, false, SEQ>(K, false);
+    return seq ? decode_kernel<KT, kModeSums, false, true, false> : decode_kernel<KT, kModeSums, false, false, false>;
   default:
     return nullptr;
   }
 }
 
+// Beta stride 2 (every second beta row stored, the others recomputed in the alpha sweep): array-mode IBD decode of
+// the family members it is built for.
 bool halfAvailable(int mode, const fsmc_model* m)
 {
-  return mode == kModeIbd && !m->sequence && m->K == 69;
+  return mode == kModeIbd && !m->sequence && halfBuilt(familyMember(m));
 }
 
-// The wide-model kernel (four lanes per pair, fsmc_kernels_q4.h): 70 <= K <= 256, array mode, IBD and dump
+// The wide-model kernel (four lanes per pair, fsmc_kernels_q4.h): 80 < K <= 256, array mode, IBD, per-pair and dump
 // consumers.  fsmc_model_create pads such a model's rows to KP = 128, 192 or 256 floats = 4 x the states per lane.
 bool quarterLanes(int mode, const fsmc_model* m)
 {
-  return m->K > 69 && m->K <= 4 * kQ4MaxStates && !m->sequence &&
+  return m->K > 80 && m->K <= 4 * kQ4MaxStates && !m->sequence &&
          (mode == kModeIbd || mode == kModeDump || mode == kModePerPair) &&
          (m->KP == 128 || m->KP == 192 || m->KP == 256);
 }
@@ -224,6 +243,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
     if (mode == kModeIbd) {
       m->ctx->lastStride = 1;
     }
+    m->ctx->lastMember = -(m->KP / 4);
     return m->KP == 128 ? pickQuarterKernel<32>(mode, track)
                         : m->KP == 192 ? pickQuarterKernel<48>(mode, track) : pickQuarterKernel<64>(mode, track);
   }
@@ -231,7 +251,24 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
   if (mode == kModeIbd) {
     m->ctx->lastStride = half ? 2 : 1;
   }
-  return m->sequence ? pickKernel<true>(mode, track, m->K, false) : pickKernel<false>(mode, track, m->K, half);
+  const int member = familyMember(m);
+  m->ctx->lastMember = member;
+  switch (member) {
+  case 16:
+    return pickMember<16>(mode, track, m->sequence, half);
+  case 32:
+    return pickMember<32>(mode, track, m->sequence, half);
+  case 48:
+    return pickMember<48>(mode, track, m->sequence, half);
+  case 64:
+    return pickMember<64>(mode, track, m->sequence, half);
+  case 69:
+    return pickMember<69>(mode, track, m->sequence, half);
+  case 80:
+    return pickMember<80>(mode, track, m->sequence, half);
+  default:
+    return pickMember<0>(mode, track, m->sequence, false);
+  }
 }
 
 struct LaunchPlan {
@@ -270,7 +307,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     const size_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
     L = std::max<size_t>(L, aEnd - g.from);
   }
-  const size_t K4 = q4 ? (size_t)m->KP / 16 : (size_t)(m->K + 3) / 4; // q4: a lane stores KP/4 states
+  // float4 per lane of a stored K-vector: q4 lanes hold KP/4 states; a padded family member stores its ghosts too
+  const int member = familyMember(m);
+  const size_t K4 = q4 ? (size_t)m->KP / 16 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes);
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
@@ -547,6 +586,15 @@ int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_c
   return FSMC_OK;
 }
 
+int fsmc_ctx_last_kernel(const fsmc_ctx* ctx, int32_t* member)
+{
+  if (!ctx || !member) {
+    return FSMC_EINVAL;
+  }
+  *member = ctx->lastMember;
+  return FSMC_OK;
+}
+
 int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
 {
   if (!ctx || !d || !out) {
@@ -589,7 +637,7 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   m->ctx = ctx;
   m->K = d->K;
   m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
-  if (d->K > 69) {
+  if (d->K > 80) {
     // wide models: four lanes per pair hold KP/4 states each (fsmc_kernels_q4.h); the padding states are ghosts
     m->KP = d->K <= 128 ? 128 : d->K <= 192 ? 192 : 256;
   }
@@ -1006,9 +1054,6 @@ int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sum
     if (g.from != 0 || g.to != (uint32_t)m->S) {
       return fail(ctx, FSMC_EINVAL, "posterior sums need whole-sequence groups (HMM.cpp:1052)");
     }
-  }
-  if ((size_t)m->K * 65 * sizeof(float) > (size_t)((m->K > 69 ? kMaxGenericK : 69) + 3) / 4 * kWave * sizeof(float4)) {
-    return fail(ctx, FSMC_EUNSUPPORTED, "too many states for the sums transposition tile");
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   KernelFn fn = pickKernel(kModeSums, false, m);

@@ -1,0 +1,21 @@
+// fsmc_inst.hip -- one family member's kernel instantiations (see fsmc_instances.h).
+// Compiled with -DFSMC_INSTANCE_KT=<n> (lane-per-pair member) or -DFSMC_INSTANCE_Q4=<n> (states per lane of the
+// four-lanes-per-pair kernel); fastsmc_amd/build.py drives one hipcc per member, in parallel.
+#include "fsmc_instances.h"
+
+namespace fsmc
+{
+#if defined(FSMC_INSTANCE_KT)
+FSMC_KT_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
+#if FSMC_INSTANCE_KT == 16 || FSMC_INSTANCE_KT == 32 || FSMC_INSTANCE_KT == 48 || FSMC_INSTANCE_KT == 64 || FSMC_INSTANCE_KT == 69
+static_assert(halfBuilt(FSMC_INSTANCE_KT), "keep halfBuilt() and this list in step");
+FSMC_KT_HALF_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
+#else
+static_assert(!halfBuilt(FSMC_INSTANCE_KT), "keep halfBuilt() and this list in step");
+#endif
+#elif defined(FSMC_INSTANCE_Q4)
+FSMC_Q4_KERNELS(FSMC_DEFINE_Q4, FSMC_INSTANCE_Q4)
+#else
+#error "define FSMC_INSTANCE_KT or FSMC_INSTANCE_Q4"
+#endif
+} // namespace fsmc

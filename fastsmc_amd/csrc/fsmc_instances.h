@@ -1,0 +1,70 @@
+// fsmc_instances.h -- the kernel instantiations of libfastsmc_hip.so and where each is compiled.
+//
+// The decode kernels are templates (fsmc_kernels.h, fsmc_kernels_q4.h); every instantiation is a fully unrolled
+// kernel of several thousand instructions, so they are compiled in separate translation units, in parallel:
+// fsmc_inst.hip is built once per family member (-DFSMC_INSTANCE_KT=<n> / -DFSMC_INSTANCE_Q4=<n>) and defines the
+// instantiations of that member; fsmc_capi.hip only sees the declarations below and picks a function pointer.
+//
+// Lane-per-pair family (decode_kernel<KT, MODE, TRACK, SEQ, HALF>):
+//   KT = 69               the 69-state models of the reference's decoding-quantities files, no padding
+//   KT = 16, 32, 48, 64, 80   every other model with K <= 80: padded with ghost states to the next member
+//   KT = 0                runtime K (wide models in the modes the four-lanes-per-pair kernel does not have)
+// Four-lanes-per-pair kernel (decode_kernel_q4<KQ, MODE, TRACK>): 80 < K <= 256, KQ = 32, 48, 64 states per lane.
+#pragma once
+
+#include "fsmc_kernels.h"
+#include "fsmc_kernels_q4.h"
+
+namespace fsmc
+{
+
+// beta stride 2 needs three K-vectors in a lane's registers: built for the members it fits
+constexpr bool halfBuilt(const int KT)
+{
+  return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 69;
+}
+
+#define FSMC_KT_KERNELS(X, KT)                                                                                         \
+  X(KT, kModeIbd, true, false, false)                                                                                  \
+  X(KT, kModeIbd, false, false, false)                                                                                 \
+  X(KT, kModeIbd, true, true, false)                                                                                   \
+  X(KT, kModeIbd, false, true, false)                                                                                  \
+  X(KT, kModeDump, false, false, false)                                                                                \
+  X(KT, kModeDump, false, true, false)                                                                                 \
+  X(KT, kModePerPair, false, false, false)                                                                             \
+  X(KT, kModePerPair, false, true, false)                                                                              \
+  X(KT, kModeSums, false, false, false)                                                                                \
+  X(KT, kModeSums, false, true, false)
+#define FSMC_KT_HALF_KERNELS(X, KT)                                                                                    \
+  X(KT, kModeIbd, true, false, true)                                                                                   \
+  X(KT, kModeIbd, false, false, true)
+#define FSMC_Q4_KERNELS(X, KQ)                                                                                         \
+  X(KQ, kModeIbd, true)                                                                                                \
+  X(KQ, kModeIbd, false)                                                                                               \
+  X(KQ, kModeDump, false)                                                                                              \
+  X(KQ, kModePerPair, false)
+
+#define FSMC_DECLARE_KT(KT, MODE, TRACK, SEQ, HALF)                                                                    \
+  extern template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
+#define FSMC_DEFINE_KT(KT, MODE, TRACK, SEQ, HALF)                                                                     \
+  template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
+#define FSMC_DECLARE_Q4(KQ, MODE, TRACK) extern template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
+#define FSMC_DEFINE_Q4(KQ, MODE, TRACK) template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
+
+// every member of the library (build.py compiles fsmc_inst.hip once for each entry of these two lists)
+#define FSMC_ALL_KT(Y) Y(0) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80)
+#define FSMC_ALL_Q4(Y) Y(32) Y(48) Y(64)
+
+#if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_Q4)
+#define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)
+FSMC_ALL_KT(FSMC_DECLARE_MEMBER)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 16)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 32)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 48)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 64)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 69)
+#define FSMC_DECLARE_Q4_MEMBER(KQ) FSMC_Q4_KERNELS(FSMC_DECLARE_Q4, KQ)
+FSMC_ALL_Q4(FSMC_DECLARE_Q4_MEMBER)
+#endif
+
+} // namespace fsmc

@@ -102,16 +102,18 @@ struct KParams {
 #define FSMC_GCN_ASM(...) ((void)0)
 #endif
 
+// (the forms without an offset serve the runtime-K steps, whose block loops are real loops with spilled registers all
+//  around: they wait inside the same asm statement, so that nothing can touch a destination in flight)
 __device__ __forceinline__ f32x4 sload4(cfloat_p p)
 {
   f32x4 v = {};
-  FSMC_GCN_ASM("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p));
+  FSMC_GCN_ASM("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
   return v;
 }
 __device__ __forceinline__ f32x8 sload8(cfloat_p p)
 {
   f32x8 v = {};
-  FSMC_GCN_ASM("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p));
+  FSMC_GCN_ASM("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
   return v;
 }
 // The same loads with the block's byte offset as an instruction immediate (compile-time K: the unrolled block
@@ -163,7 +165,7 @@ __device__ __forceinline__ void holdTouched(Touched& a)
 __device__ __forceinline__ f32x16 sload16(cfloat_p p)
 {
   f32x16 v = {};
-  FSMC_GCN_ASM("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p));
+  FSMC_GCN_ASM("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
   return v;
 }
 __device__ __forceinline__ void swait(f32x8& a, f32x8& b)
@@ -590,20 +592,46 @@ template <int COUNT> __device__ __forceinline__ void heldRow(const Touched& t)
 // What a backward step has in flight when it opens: its first operand block (the top states of Ush and RR), the
 // warm-up of those rows' other lines and the emission values of the same states.  Requested by beta_issue_pk ahead of
 // operand-free work (the scaling multiply and the row store of the step before), consumed by beta_core_pk.
+// Operand loads of the packed steps.  SY = false: asynchronous (the value is final behind the next operand wait; the
+// compiled code is checked for instructions that touch the destination earlier, tools/check_inflight_sgprs.py).
+// SY = true: load and wait in ONE asm statement -- nothing can come between, at the price of the latency at every
+// block.  The sequence-mode kernels use it: their extra live scalars made the register allocator spill operand
+// blocks right behind their loads (v_writelane of registers still in flight) in some instantiations.
+template <int N, bool SY> struct LD {
+  typedef typename SV<N>::T T;
+  static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState)
+  {
+    if constexpr (!SY) {
+      return SV<N>::loadAt(p, firstState);
+    } else {
+      T v = {};
+      if constexpr (N == 16) {
+        FSMC_GCN_ASM("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "i"(firstState * 4));
+      } else if constexpr (N == 8) {
+        FSMC_GCN_ASM("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "i"(firstState * 4));
+      } else {
+        FSMC_GCN_ASM("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "i"(firstState * 4));
+      }
+      return v;
+    }
+  }
+};
+
 template <int KT> struct BetaOps {
   typename SV<kKB>::T u, rr;
   Touched tu, trr;
   EmisBlk<kKB> em;
 };
 
-template <int KT> __device__ __forceinline__ void beta_issue_pk(BetaOps<KT>& o, cfloat_p rowSet, const float4* e)
+template <int KT, bool SY = false>
+__device__ __forceinline__ void beta_issue_pk(BetaOps<KT>& o, cfloat_p rowSet, const float4* e)
 {
   constexpr int KPc = ((KT + kKPad - 1) / kKPad) * kKPad;
   constexpr int NB = (KT + kKB - 1) / kKB;
   constexpr int NLINES = KPc / 16;
-  o.u = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (NB - 1) * kKB);
-  o.rr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (NB - 1) * kKB);
-  if constexpr (kTouch) {
+  o.u = LD<kKB, SY>::loadAt(rowSet, kRowUsh * KPc + (NB - 1) * kKB);
+  o.rr = LD<kKB, SY>::loadAt(rowSet, kRowRR * KPc + (NB - 1) * kKB);
+  if constexpr (kTouch && !SY) {
     touchRow<0, NLINES - 1>(o.tu, rowSet, kRowUsh * KPc);
     touchRow<0, NLINES - 1>(o.trr, rowSet, kRowRR * KPc);
   }
@@ -612,7 +640,7 @@ template <int KT> __device__ __forceinline__ void beta_issue_pk(BetaOps<KT>& o, 
 
 // The recurrences of one backward step: on entry b = beta of site pos+1 (scaled), on exit w = the un-normalised
 // beta of site pos and the return value its sum over the states (k ascending from 0.f); b is used up.
-template <int KT, int KA, bool GHOST>
+template <int KT, int KA, bool GHOST, bool SY = false>
 __device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], BetaOps<KT>& ops, cfloat_p rowSet,
                                               const float4* e, cfloat_p ghostMask, Diag& dg)
 {
@@ -637,7 +665,7 @@ __device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], Be
     FSMC_WAIT_OPERANDS(dg.waitCycles);
     if (blk == NB - 1) {
       landed(ops.u, ops.rr);
-      if constexpr (kTouch) {
+      if constexpr (kTouch && !SY) {
         heldRow<NLINES - 1>(ops.tu);
         heldRow<NLINES - 1>(ops.trr);
       }
@@ -651,18 +679,18 @@ __device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], Be
       em = nem;
     }
     if (blk > 0) {
-      nu = SV<kKB>::loadAt(rowSet, kRowUsh * KPc + (blk - 1) * kKB);
-      nrr = SV<kKB>::loadAt(rowSet, kRowRR * KPc + (blk - 1) * kKB);
+      nu = LD<kKB, SY>::loadAt(rowSet, kRowUsh * KPc + (blk - 1) * kKB);
+      nrr = LD<kKB, SY>::loadAt(rowSet, kRowRR * KPc + (blk - 1) * kKB);
       nem = readEmis<kKB>(e, blk - 1);
     } else {
-      d = SV<kKB>::loadAt(rowSet, kRowD * KPc);
-      bt = SV<kKB>::loadAt(rowSet, kRowB * KPc);
-      if constexpr (kTouch) {
+      d = LD<kKB, SY>::loadAt(rowSet, kRowD * KPc);
+      bt = LD<kKB, SY>::loadAt(rowSet, kRowB * KPc);
+      if constexpr (kTouch && !SY) {
         touchRow<1, NLINES - 1>(td, rowSet, kRowD * KPc);
         touchRow<1, NLINES - 1>(tbt, rowSet, kRowB * KPc);
       }
       if constexpr (GHOST && NB == 1) {
-        mk = SV<kKB>::loadAt(ghostMask, 0);
+        mk = LD<kKB, SY>::loadAt(ghostMask, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -720,7 +748,7 @@ __device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], Be
       bt = nbt;
     } else {
       landed(d, bt);
-      if constexpr (kTouch) {
+      if constexpr (kTouch && !SY) {
         heldRow<NLINES - 1>(td);
         heldRow<NLINES - 1>(tbt);
       }
@@ -731,11 +759,11 @@ __device__ __forceinline__ float beta_core_pk(float (&b)[KA], float (&w)[KA], Be
       }
     }
     if (blk + 1 < NB) {
-      nd = SV<kKB>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKB);
-      nbt = SV<kKB>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKB);
+      nd = LD<kKB, SY>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKB);
+      nbt = LD<kKB, SY>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKB);
       if constexpr (GHOST) {
         if (blk + 1 == NB - 1) {
-          mk = SV<kKB>::loadAt(ghostMask, (NB - 1) * kKB);
+          mk = LD<kKB, SY>::loadAt(ghostMask, (NB - 1) * kKB);
         }
       }
     }
@@ -797,13 +825,13 @@ template <int KT, int KA> __device__ __forceinline__ void scale_pk(float (&v)[KA
 }
 
 // A whole backward step in one piece (the sequence-mode passes and the recomputed rows of beta stride 2).
-template <int KT, int KA, bool SCALE, bool GHOST>
+template <int KT, int KA, bool SCALE, bool GHOST, bool SY = false>
 __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfloat_p rowSet, const float4* e,
                                              cfloat_p ghostMask, Diag& dg)
 {
   BetaOps<KT> ops;
-  beta_issue_pk<KT>(ops, rowSet, e);
-  const float sum = beta_core_pk<KT, KA, GHOST>(b, w, ops, rowSet, e, ghostMask, dg);
+  beta_issue_pk<KT, SY>(ops, rowSet, e);
+  const float sum = beta_core_pk<KT, KA, GHOST, SY>(b, w, ops, rowSet, e, ghostMask, dg);
   if constexpr (SCALE) {
     scale_pk<KT, KA>(b, w, sum);
   } else {
@@ -816,7 +844,7 @@ __device__ __forceinline__ void beta_step_pk(float (&b)[KA], float (&w)[KA], cfl
 
 // Forward.  The suffix sums are kept one slot down (w[k] = alphaC[k+1]) so that B[k]*alphaC[k+1] pairs up with the
 // other products of state k; alphaC[0] is never used (HMM.cpp:799-830).
-template <int KT, int KA, bool SCALE = true>
+template <int KT, int KA, bool SCALE = true, bool SY = false>
 __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cfloat_p rowSet, cfloat_p cR,
                                               const float4* e, Diag& dg)
 {
@@ -826,10 +854,10 @@ __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cf
   typedef typename SV<kKBF>::T SVec;
   constexpr int NB = (K + kKBF - 1) / kKBF; // operand blocks (scalar loads + emission values, one block ahead)
   constexpr int NLINES = KPc / 16;
-  SVec d = SV<kKBF>::loadAt(rowSet, kRowD * KPc), bt = SV<kKBF>::loadAt(rowSet, kRowB * KPc),
-       u = SV<kKBF>::loadAt(rowSet, kRowU * KPc), c4 = SV<kKBF>::loadAt(cR, 0);
+  SVec d = LD<kKBF, SY>::loadAt(rowSet, kRowD * KPc), bt = LD<kKBF, SY>::loadAt(rowSet, kRowB * KPc),
+       u = LD<kKBF, SY>::loadAt(rowSet, kRowU * KPc), c4 = LD<kKBF, SY>::loadAt(cR, 0);
   Touched td, tbt, tu;
-  if constexpr (kTouch) {
+  if constexpr (kTouch && !SY) {
     touchRow<1, NLINES - 1>(td, rowSet, kRowD * KPc);
     touchRow<1, NLINES - 1>(tbt, rowSet, kRowB * KPc);
     touchRow<1, NLINES - 1>(tu, rowSet, kRowU * KPc);
@@ -858,17 +886,17 @@ __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cf
       em = nem;
     } else {
       landed(d, bt, u, c4);
-      if constexpr (kTouch) {
+      if constexpr (kTouch && !SY) {
         heldRow<NLINES - 1>(td);
         heldRow<NLINES - 1>(tbt);
         heldRow<NLINES - 1>(tu);
       }
     }
     if (blk + 1 < NB) {
-      nd = SV<kKBF>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKBF);
-      nbt = SV<kKBF>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKBF);
-      nu = SV<kKBF>::loadAt(rowSet, kRowU * KPc + (blk + 1) * kKBF);
-      nc = SV<kKBF>::loadAt(cR, (blk + 1) * kKBF);
+      nd = LD<kKBF, SY>::loadAt(rowSet, kRowD * KPc + (blk + 1) * kKBF);
+      nbt = LD<kKBF, SY>::loadAt(rowSet, kRowB * KPc + (blk + 1) * kKBF);
+      nu = LD<kKBF, SY>::loadAt(rowSet, kRowU * KPc + (blk + 1) * kKBF);
+      nc = LD<kKBF, SY>::loadAt(cR, (blk + 1) * kKBF);
       nem = readEmis<kKBF>(e, blk + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -947,27 +975,29 @@ template <int KT> __device__ __forceinline__ cfloat_p rowSetOf(const Tables& t, 
   return t.rowSets + (size_t)row * (kRowSetParts * KPc);
 }
 
-template <int KT, int KA, bool SCALE = true>
+template <int KT, int KA, bool SCALE = true, bool SY = false>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], const Tables& t, const int row,
                                           const float4* e, Diag& dg)
 {
   if constexpr (KT > 0 && kPacked) {
-    beta_step_pk<KT, KA, SCALE, kGhost<KT>>(b, w, rowSetOf<KT>(t, row), e, t.ghostMask, dg);
+    beta_step_pk<KT, KA, SCALE, kGhost<KT>, SY>(b, w, rowSetOf<KT>(t, row), e, t.ghostMask, dg);
   } else {
     const size_t o = (size_t)row * t.KP;
     beta_step_1<KT, KA, SCALE>(K, b, w, t.D + o, t.B + o, t.U + o, t.RR + o, e, dg);
+    waitLgkm0(); // (runtime-K loops: closes the paths on which a block loop would run zero times)
   }
 }
 
-template <int KT, int KA, bool SCALE = true>
+template <int KT, int KA, bool SCALE = true, bool SY = false>
 __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], const Tables& t, const int row,
                                            const float4* e, Diag& dg)
 {
   if constexpr (KT > 0 && kPacked) {
-    alpha_step_pk<KT, KA, SCALE>(a, w, rowSetOf<KT>(t, row), t.cR, e, dg);
+    alpha_step_pk<KT, KA, SCALE, SY>(a, w, rowSetOf<KT>(t, row), t.cR, e, dg);
   } else {
     const size_t o = (size_t)row * t.KP;
     alpha_step_1<KT, KA, SCALE>(K, a, w, t.D + o, t.B + o, t.U + o, t.cR, e, dg);
+    waitLgkm0();
   }
 }
 
@@ -1133,12 +1163,17 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   constexpr int NC = SEQ ? 4 : 3;                         // emission rows per site: 3 observation classes (+ gap)
   constexpr int NL = (NC * E4A + kWave - 1) / kWave;      // float4 per lane to stage one site's rows
   const int K = KT > 0 ? KT : p.K;
+  // states of the model: < K for a padded family member (the states Kreal..K-1 are ghosts), otherwise K
+  const int Kreal = kGhost<KT> ? p.K : K;
   const int K4 = (K + 3) >> 2;
   const int KP = p.KP; // (a compile-time KP for fixed K measured 6 % slower on C2: keep the runtime value)
   const int E4 = KP >> 2;
 
   __shared__ float4 emisLds[2][NC * E4A]; // ring of two sites x three observation classes (+ the gap row)
-  __shared__ float4 betaLds[K4A * kWave]; // landing zone of the next site's beta row (LDS-DMA)
+  // landing zone of the next site's beta row (LDS-DMA); the sums consumer also transposes the K x 64 posterior tile
+  // through it with a row stride of 65 floats
+  constexpr int kLandF4 = (MODE == kModeSums && (KA * 65 + 3) / 4 > K4A * kWave) ? (KA * 65 + 3) / 4 : K4A * kWave;
+  __shared__ float4 betaLds[kLandF4];
 
   const int lane = threadIdx.x;
   const cfloat_p tD = (cfloat_p)p.D, tB = (cfloat_p)p.B, tU = (cfloat_p)p.U, tRR = (cfloat_p)p.RR;
@@ -1313,7 +1348,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
     auto betaGapStep = [&](float (&b)[KA], const int q, const EmisRegs& rows) {
       commitEmis(q, rows);
       const int row = tRowGapB[q];
-      beta_step<KT, KA, false>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW);
+      beta_step<KT, KA, false, SEQ>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW);
     };
     auto betaSeqStep = [&](float (&b)[KA], const int pos) {
       const int q = pos + 1;
@@ -1324,7 +1359,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       }
       const int c = obsClass(q);
       const int row = tRowSiteB[q];
-      beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+      beta_step<KT, KA, true, SEQ>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
       if (gap) {
         betaGapStep(b, pos, ev);
       }
@@ -1415,7 +1450,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
             }
             const int row = stepRowOf(q);
             const int c = obsClass(q);
-            beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+            beta_step<KT, KA, true, SEQ>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
             afterBeta(pos);
           }
         }
@@ -1561,7 +1596,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               }
               const int row = stepRowOf(q);
               const int c = obsClass(q);
-              beta_step<KT, KA>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+              beta_step<KT, KA, true, SEQ>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
               storeRow(pos, b);
             }
           }
@@ -1609,7 +1644,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         if (pos == from) {
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
-          alpha_step<KT, KA>(K, a, w, tabs, stepRowOf(pos), e, cycW);
+          alpha_step<KT, KA, true, SEQ>(K, a, w, tabs, stepRowOf(pos), e, cycW);
         }
         if constexpr (SEQ) {
           // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step
@@ -1617,8 +1652,8 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           if (pos < to - 1) {
             commitEmis(pos + 1, ev);
             const int row = tRowGapF[pos + 1];
-            alpha_step<KT, KA, false>(K, a, w, tabs, row, &emisLds[(pos + 1) & 1][3 * E4],
-                                      cycW);
+            alpha_step<KT, KA, false, SEQ>(K, a, w, tabs, row, &emisLds[(pos + 1) & 1][3 * E4],
+                                            cycW);
           }
         }
 
@@ -1775,7 +1810,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (int kk = lane; kk < K; kk += kWave) {
+          for (int kk = lane; kk < Kreal; kk += kWave) {
             float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
             for (int v = 0; v < nPairsInGroup; ++v) {
               const float q = tile[kk * 65 + v];
@@ -1791,7 +1826,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
                 }
               }
             }
-            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + kk;
+            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + kk;
             if (p.flags & FSMC_WANT_SUMS) acc[0] += s;
             if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
               acc[p.sumsPlane] += s00;
@@ -1813,10 +1848,12 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         }
 
         if (MODE == kModeDump) {
-          float* out = p.dumpOut + p.dumpOffsets[g] + (size_t)(pos - from) * K * kWave + lane;
+          float* out = p.dumpOut + p.dumpOffsets[g] + (size_t)(pos - from) * Kreal * kWave + lane;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            out[(size_t)k * kWave] = valid ? w[k] * cq : 0.f;
+            if (!kGhost<KT> || k < Kreal) {
+              out[(size_t)k * kWave] = valid ? w[k] * cq : 0.f;
+            }
           }
         }
 
@@ -1929,18 +1966,5 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   }
 }
 
-
-// Sum of the per-wave accumulator planes in slot order (fixed order => reproducible fp32 result).
-__global__ void reduce_planes_kernel(const float* __restrict__ planes, float* __restrict__ out, size_t n, int nSlots,
-                                     size_t slotStride)
-{
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int sl = 0; sl < nSlots; ++sl) {
-      s = s + planes[(size_t)sl * slotStride + i];
-    }
-    out[i] = s;
-  }
-}
 
 } // namespace fsmc

@@ -127,13 +127,17 @@ int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes);
 int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites);
 /* Tuning: beta stride of the IBD decode.  1 = every beta row of a chunk goes through HBM (8K bytes per pair-site);
  * 2 = every second row does and the alpha sweep recomputes the others from their successor (4K bytes per
- * pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (K = 69, array mode), else 1.
+ * pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (array mode, K <= 69), else 1.
  * Results do not depend on it.  fsmc_ctx_last_beta_stride reports what the last IBD launch used. */
 int fsmc_ctx_set_beta_stride(fsmc_ctx* ctx, uint32_t stride);
 int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
 /* How the last launch was laid out: sites per chunk (= the longest window when every beta row fitted), chunks per
  * window, resident waves. */
 int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_chunks, int32_t* n_slots);
+/* Which kernel family member the last launch ran: n > 0 = the lane-per-pair kernel compiled for n states (69, or
+ * the padded members 16, 32, 48, 64, 80), n < 0 = the four-lanes-per-pair kernel with -n states per lane
+ * (80 < K <= 256), 0 = the runtime-K kernel (wide models in the modes the four-lane kernel does not have). */
+int fsmc_ctx_last_kernel(const fsmc_ctx* ctx, int32_t* member);
 
 /* ---- resident inputs ---- */
 int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* desc, fsmc_model** out);

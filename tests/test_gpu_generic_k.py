@@ -1,6 +1,8 @@
-"""Models other than K = 69 against the oracle, all output modes: the runtime-K kernel instantiation (K < 69, and the
-per-pair / sum consumers of any K) and the wide-model kernel (70 <= K <= 256: four lanes per pair, 32 / 48 / 64 states
-per lane, padded with ghost states -- K = 70, 100, 128 exactly, 130, 192 exactly, 200, 256 exactly)."""
+"""Models other than K = 69 against the oracle, all output modes.  K <= 80 runs the lane-per-pair kernel compiled for
+the next family member (16, 32, 48, 64, 80 states; the padding states are ghosts -- K = 2, 5, 16 exactly, 17, 33, 50, 64
+exactly, 65, 70, 80 exactly); 80 < K <= 256 the wide-model kernel (four lanes per pair, 32 / 48 / 64 states per lane,
+ghost-padded -- K = 81, 100, 128 exactly, 130, 192 exactly, 200, 256 exactly), whose sums over pairs still come from the
+runtime-K kernel.  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
 import numpy as np
 import pytest
 
@@ -20,7 +22,15 @@ def _problem(K, n_hap=64, S=200, seed=11):
     return pm, bits, folded
 
 
-@pytest.mark.parametrize("K", [5, 16, 70, 100, 128, 130, 192, 200, 256])
+def _member(K):
+    if K == 69:
+        return 69
+    if K <= 80:
+        return (K + 15) // 16 * 16
+    return -(32 if K <= 128 else 48 if K <= 192 else 64)
+
+
+@pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 50, 64, 65, 70, 80, 81, 100, 128, 130, 192, 200, 256])
 def test_generic_kernel_matches_oracle(K):
     pm, bits, folded = _problem(K)
     pairs = O.enumerate_all_pairs(32)[:96]
@@ -32,6 +42,8 @@ def test_generic_kernel_matches_oracle(K):
     # IBD records (mean + MAP)
     want = O.decode_pairs_ibd(pm, folded, pairs, batch_size=64)
     got = ctx.decode_ibd(model, pr, groups)
+    assert ctx.last_kernel() == _member(K)
+    assert ctx.last_beta_stride() == (2 if K <= 64 else 1)
     assert got.size == want.size
     for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"),
                           ("post_mean", "postMean"), ("map", "map")):
@@ -39,20 +51,46 @@ def test_generic_kernel_matches_oracle(K):
     # posterior, per-pair mean/MAP and sums for the first group
     ctx.upload_worklist(pr[:64], capi.whole_sequence_groups(64, pm.S))
     post = ctx.decode_posteriors(model)[0]
+    assert ctx.last_kernel() == _member(K)
     ob = np.stack([folded[a] ^ folded[b] for a, b in pairs[:64]])
     hb = np.stack([folded[a] & folded[b] for a, b in pairs[:64]])
     wpost, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
     np.testing.assert_array_equal(post, wpost)
     mean, mp = ctx.decode_per_pair(model, pm.exp_times)
+    assert ctx.last_kernel() == _member(K)
     wmean, wmap, _ = O.per_pair_output(pm, wpost, 64)
     np.testing.assert_array_equal(mean, wmean)
     np.testing.assert_array_equal(mp, wmap)
-    if K <= 250:
-        s, _ = ctx.decode_sums(model)
-        wsum = np.zeros((pm.S, pm.K), np.float32)
-        O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
-        np.testing.assert_array_equal(s, wsum)
+    s, _ = ctx.decode_sums(model)  # (K = 256 included: the transposition tile is sized for it)
+    assert ctx.last_kernel() == (_member(K) if K <= 80 else 0)
+    wsum = np.zeros((pm.S, pm.K), np.float32)
+    O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
+    np.testing.assert_array_equal(s, wsum)
     ctx.close()
+
+
+@pytest.mark.parametrize("K", [12, 40, 64])
+def test_padded_members_stride_and_chunking(K):
+    """The padded members through the checkpoint / rebuild layout and both beta strides: same records as the oracle."""
+    pm, bits, folded = _problem(K, S=333, seed=5)
+    pairs = O.enumerate_all_pairs(32)[:70]
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    want = O.decode_pairs_ibd(pm, folded, pairs, batch_size=64)
+    for stride in (1, 2):
+        for chunk in (0, 48):
+            ctx = capi.Context(0)
+            model = ctx.create_model(pm)
+            ctx.upload_haps(bits, pm.S)
+            ctx.set_beta_stride(stride)
+            if chunk:
+                ctx.set_chunk_sites(chunk)
+            got = ctx.decode_ibd(model, pr, capi.whole_sequence_groups(len(pairs), pm.S))
+            assert ctx.last_beta_stride() == stride
+            assert got.size == want.size
+            for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"),
+                                  ("post_mean", "postMean"), ("map", "map")):
+                np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f"{f_got} stride {stride} chunk {chunk}")
+            ctx.close()
 
 
 def test_too_many_states_is_rejected():

@@ -1,10 +1,24 @@
 #!/bin/bash
 # Builds an experimental variant of the HIP library (same C ABI) into fastsmc_amd/variants/lib<name>.so;
 # run it with FSMC_HIP_LIB=fastsmc_amd/variants/lib<name>.so python bench.py ...
+# Only the members a C2-style bench needs are built: fsmc_capi.hip + the K = 69 member (+ the others as stubs is not
+# possible: the selection code references them), so every member is compiled -- in parallel.
 # Usage: tools/build_variant.sh <name> [extra hipcc flags, e.g. -DFSMC_PHASE_STAMPS]
 set -eu
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-mkdir -p $ROOT/fastsmc_amd/variants
-hipcc -std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wno-pass-failed \
-  "$@" -o $ROOT/fastsmc_amd/variants/lib$NAME.so $ROOT/fastsmc_amd/csrc/fsmc_capi.hip
+OUT=$ROOT/fastsmc_amd/variants
+OBJ=$OUT/obj_$NAME
+mkdir -p $OBJ
+FLAGS="-std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wno-pass-failed -c"
+PIDS=""
+hipcc $FLAGS "$@" -o $OBJ/capi.o $ROOT/fastsmc_amd/csrc/fsmc_capi.hip & PIDS="$PIDS $!"
+for K in 0 16 32 48 64 69 80; do
+  hipcc $FLAGS "$@" -DFSMC_INSTANCE_KT=$K -o $OBJ/kt$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
+done
+for K in 32 48 64; do
+  hipcc $FLAGS "$@" -DFSMC_INSTANCE_Q4=$K -o $OBJ/q4_$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
+done
+for P in $PIDS; do wait $P; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib$NAME.so $OBJ/*.o
+rm -rf $OBJ

@@ -51,9 +51,10 @@ class Block:
 
 
 def blocks_of(body: str):
+    """Basic blocks: a block starts at a label and after every branch instruction."""
     blocks = [Block("entry")]
-    by_name = {"entry": blocks[0]}
     in_asm = False
+    n_anon = 0
     for ln_no, ln in enumerate(body.split("\n")):
         s = ln.strip()
         if s.startswith(";;#ASMSTART"):
@@ -64,16 +65,20 @@ def blocks_of(body: str):
             continue
         m = re.match(r"^(\.LBB\d+_\d+):", ln)
         if m:
-            b = Block(m.group(1))
-            blocks.append(b)
-            by_name[b.name] = b
+            blocks.append(Block(m.group(1)))
             continue
         if not s or s.startswith((";", ".")) or s.endswith(":"):
             continue
         blocks[-1].ins.append((ln_no, s, in_asm))
+        op = s.split()[0]
+        if op == "s_branch" or op.startswith("s_cbranch") or op in ("s_endpgm", "s_setpc_b64"):
+            n_anon += 1
+            blocks.append(Block(f".anon{n_anon}"))
+    by_name = {b.name: b for b in blocks}
     for i, b in enumerate(blocks):
         falls = True
-        for _, s, _ in b.ins:
+        if b.ins:
+            s = b.ins[-1][1]
             op = s.split()[0]
             if op == "s_branch":
                 b.succ.append(s.split()[1])
