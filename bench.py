@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- pairs/s of the pairwise HMM decode path on MI355X, against its HBM roofline.
 
-Workload (BASELINE.json configs[1]): synthetic 1000 haplotypes x 50000 sites, 69 states, all
-499500 haplotype pairs, FastSMC-mode output (IBD segments + posterior-mean / MAP ages, no hashing),
-one GPU.  A "step" = one decode of the whole pair list with every input (model tables, packed
-haplotypes, work list) already resident in HBM; the step ends when the ordered IBD records are back
-on the host.  With N > 1 (one process per GPU under torch.distributed.run) every rank decodes the
-full pair list of its own synthetic cohort (seed + rank) -- weak scaling, no data-path collective --
-and the records are gathered to rank 0 over RCCL at the end of each step.
+N = 1 (default; BASELINE.json configs[1], "C2"): synthetic 1000 haplotypes x 50000 sites, 69 states, all 499500
+haplotype pairs, FastSMC-mode output (IBD segments + posterior-mean / MAP ages, no hashing), one GPU.
 
-Prints ONE JSON line (see the contract in the task description) with `roofline` and `cpu_baseline`.
+N > 1 (one process per GPU under torch.distributed.run; BASELINE.json configs[2], "C3"): STRONG scaling of ONE
+problem -- synthetic 10000 haplotypes x 100000 sites, 69 states, a fixed seeded sub-list of 2^20 of the 49 995 000
+pairs in the reference's enumeration order.  The work list is cut into contiguous shards of equal pair-site weight
+(whole 64-pair groups: the reference's own job decomposition, HMM.cpp:310-321), every rank holds the model and the
+packed haplotypes, there is no collective on the data path, and the variable-length IBD records are gathered to
+rank 0 over RCCL at the end of each step.  `--workload c3` runs the same list on one GPU (the N = 1 point of the
+strong-scaling curve; profiles/ keeps that measurement and the N > 1 line quotes it when it is of this build).
+
+A "step" = one decode of the whole pair list with every input (model tables, packed haplotypes, work list) already
+resident in HBM; the step ends when the ordered IBD records are back on the host of rank 0.
+
+Prints ONE JSON line (see the contract in the task description) with `roofline` and, at N = 1, `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -26,31 +32,41 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); ~6.3e12 is the measured achievable
+METRIC = "haplotype-pairs decoded/sec (whole node) + GB/s vs HBM roofline, 69-state HMM"
+C3_PAIRS = 1 << 20
+C3_SEED = 20260
 
 
-def measured_traffic(n_hap: int, n_sites: int, K: int, beta_stride: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01c_traffic.json for beta stride 2, profiles/r01_traffic.json for stride 1: separate --pmc FETCH_SIZE /
-    WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction).  PMC collection cannot run inside the timed process, so the
-    figure is the committed measurement; it is reported only for the workload and kernel it was measured on."""
-    name = {1: "r01_traffic.json", 2: "r01c_traffic.json"}.get(beta_stride)
-    if (n_hap, n_sites, K) != (1000, 50000, 69) or name is None:
-        return None
-    path = os.path.join(ROOT, "profiles", name)
+def lib_hash() -> str:
+    from fastsmc_amd import build
+
+    return build.hip_source_hash()
+
+
+def committed_measurement(name: str):
+    """A measurement of THIS build kept under profiles/ (PMC traffic, the one-GPU point of the strong-scaling
+    curve): the file carries the hash of the HIP sources it was taken with and is ignored when they have changed."""
     try:
-        return float(json.load(open(path))["hbm_bytes_per_launch"])
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
+    return d if d.get("lib_hash") == lib_hash() else None
 
 
-def build_problem(n_hap: int, n_sites: int, K: int, seed: int):
-    """Synthetic cohort + model, prepared by the product's own host code (C++ Data/HMM constructors)."""
-    from fastsmc_amd import api, synth
+def measured_traffic(workload_key: str, beta_stride: int):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction; tools/profile_bench.sh +
+    tools/stamp_traffic.py).  PMC collection cannot run inside the timed process, so the figure is the committed
+    measurement -- reported only for the workload, stride and library build it was measured on, else null."""
+    d = committed_measurement("r02_traffic.json")
+    if not d or d.get("workload_key") != workload_key or d.get("beta_stride") != beta_stride:
+        return None
+    return float(d["hbm_bytes_per_launch"])
 
-    tables = synth.make_model_tables(K)
-    haps = synth.make_haps(n_hap, n_sites, seed=seed)
-    data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
-    dq = api.decoding_quantities_from_tables(tables)
+
+def fastsmc_params():
+    from fastsmc_amd import api
+
     p = api.DecodingParams()
     # FastSMC defaults (DecodingParams.cpp:56-73) except hashing (SURVEY.md §8d)
     p.FastSMC = True
@@ -64,7 +80,18 @@ def build_problem(n_hap: int, n_sites: int, K: int, seed: int):
     p.outputIbdSegmentLength = True
     p.useKnownSeed = True
     p.hashing = False
-    hmm = api.HMM(data, dq, p)
+    return p
+
+
+def build_problem(n_hap: int, n_sites: int, K: int, seed: int, blocked: bool = False):
+    """Synthetic cohort + model, prepared by the product's own host code (C++ Data/HMM constructors)."""
+    from fastsmc_amd import api, synth
+
+    tables = synth.make_model_tables(K)
+    haps = (synth.make_haps_blocked if blocked else synth.make_haps)(n_hap, n_sites, seed=seed)
+    data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
+    dq = api.decoding_quantities_from_tables(tables)
+    hmm = api.HMM(data, dq, fastsmc_params())
     pm = api.PreparedModelView(hmm.preparedModel())
     bits = data.packed_bits()
     return pm, bits, haps, tables
@@ -120,8 +147,11 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--haps", type=int, default=1000)
-    ap.add_argument("--sites", type=int, default=50000)
+    ap.add_argument("--workload", choices=("auto", "c2", "c3"), default="auto",
+                    help="auto: c2 at N = 1, c3 (strong scaling of one sharded list) at N > 1")
+    ap.add_argument("--haps", type=int, default=0, help="haplotypes (default: the workload's)")
+    ap.add_argument("--sites", type=int, default=0, help="sites (default: the workload's)")
+    ap.add_argument("--pairs", type=int, default=0, help="c3: pairs in the seeded sub-list (default 2^20)")
     ap.add_argument("--states", type=int, default=69)
     ap.add_argument("--chunk-sites", type=int, default=0, help="sites between beta checkpoints (0 = automatic)")
     ap.add_argument("--beta-stride", type=int, default=0,
@@ -132,6 +162,8 @@ def main() -> None:
     ap.add_argument("--ws-frac", type=float, default=0.0, help="workspace cap as a fraction of HBM (0 = default)")
     ap.add_argument("--cpu-pairs", type=int, default=-1,
                     help="pairs in the cpu_baseline sample (0 = skip, -1 = automatic: 128 per host core)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--dump-records", default="", help="rank 0 writes the last step's gathered records to this .npy")
     args = ap.parse_args()
 
     import torch
@@ -141,26 +173,61 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(1, torch.cuda.device_count())  # (rehearsals put several ranks on one card)
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend)
+    comm_device = "cuda" if args.backend == "nccl" else "cpu"
 
     from fastsmc_amd import capi
+    from fastsmc_amd.dist import all_pairs_at, gather_ibd_records, sample_pair_ordinals, shard_groups_by_weight
 
-    pm, bits, haps, _ = build_problem(args.haps, args.sites, args.states, seed=1234 + rank)
-    pairs = all_pairs(args.haps // 2)
-    n_pairs = int(pairs.shape[0])
-    groups = capi.whole_sequence_groups(n_pairs, pm.S, batch=64)
+    workload = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c3")
+    if workload == "c2":
+        # every rank its own cohort (only ever run at N = 1 by the driver; N > 1 here is a weak-scaling rehearsal)
+        n_hap, n_sites = args.haps or 1000, args.sites or 50000
+        pm, bits, haps, _ = build_problem(n_hap, n_sites, args.states, seed=1234 + rank)
+        pairs = all_pairs(n_hap // 2)
+        n_total = int(pairs.shape[0]) * world
+        lo, my_pairs = rank * int(pairs.shape[0]), pairs
+        desc = (f"synthetic {n_hap} haplotypes x {n_sites} sites, K={pm.K}, all {pairs.shape[0]} pairs per GPU, "
+                f"FastSMC-mode IBD + posterior-mean/MAP ages, no hashing")
+        scaling = "weak"
+        workload_key = f"c2:{n_hap}x{n_sites}:K{pm.K}"
+    else:
+        # ONE problem for all ranks: same seed everywhere, the work list sharded by pair-site weight
+        n_hap, n_sites = args.haps or 10000, args.sites or 100000
+        n_list = args.pairs or C3_PAIRS
+        pm, bits, haps, _ = build_problem(n_hap, n_sites, args.states, seed=1234, blocked=True)
+        ordinals = sample_pair_ordinals(n_hap // 2, n_list, C3_SEED)
+        n_total = int(ordinals.size)
+        all_groups = capi.whole_sequence_groups(n_total, pm.S, batch=64)
+        weights = all_groups["n_pairs"].astype(np.float64) * (all_groups["to"] - all_groups["from"])
+        g_lo, g_hi = shard_groups_by_weight(weights, rank, world)
+        lo = int(all_groups["first_pair"][g_lo]) if g_lo < all_groups.size else n_total
+        hi = int(all_groups["first_pair"][g_hi]) if g_hi < all_groups.size else n_total
+        pairs = my_pairs = all_pairs_at(ordinals[lo:hi])
+        tot = 2 * (n_hap // 2) ** 2 - n_hap // 2
+        desc = (f"synthetic {n_hap} haplotypes x {n_sites} sites, K={pm.K}, a seeded sub-list of {n_total} of the "
+                f"{tot} pairs (enumeration order), sharded over {world} GPU(s) by pair-site weight, FastSMC-mode IBD "
+                f"+ posterior-mean/MAP ages, no hashing")
+        scaling = "strong"
+        workload_key = f"c3:{n_hap}x{n_sites}:K{pm.K}:{n_total}"
+    n_mine = int(my_pairs.shape[0])
+    groups = capi.whole_sequence_groups(n_mine, pm.S, batch=64)
 
     if args.diag_same_row:
         pm.step_row = np.full_like(pm.step_row, pm.step_row[1])
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(device)
     model = ctx.create_model(pm)
     ctx.upload_haps(bits, pm.S)
-    ctx.upload_worklist(pairs.view(capi.PAIR_DTYPE).reshape(-1), groups)
+    ctx.upload_worklist(my_pairs.view(capi.PAIR_DTYPE).reshape(-1), groups)
     if args.chunk_sites:
         ctx.set_chunk_sites(args.chunk_sites)
     if args.ws_frac:
@@ -169,17 +236,11 @@ def main() -> None:
         ctx.set_beta_stride(args.beta_stride)
     flags = (capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP) if args.flags < 0 else args.flags
 
-    from fastsmc_amd.dist import gather_ibd_records
-
-    def gather_records(rec: np.ndarray):
-        """The path's only exchange: variable-length IBD records to rank 0 (counts, then padded payloads)."""
-        total, _ = gather_ibd_records(rec, rank * n_pairs, dist, rank, world, device="cuda")
-        return total
-
     def step():
+        """Decode this rank's shard; the path's only exchange: variable-length IBD records to rank 0."""
         ctx.decode_ibd_launch(model, flags)
         rec = ctx.decode_ibd_fetch()
-        return rec, gather_records(rec)
+        return gather_ibd_records(rec, lo, dist, rank, world, device=comm_device)
 
     def barrier():
         if dist is not None:
@@ -191,43 +252,59 @@ def main() -> None:
     kernel_ms = []
     barrier()
     t0 = time.perf_counter()
-    n_rec = 0
+    n_rec, merged = 0, None
     for _ in range(args.steps):
-        _, n_rec = step()
+        n_rec, merged = step()
         kernel_ms.append(ctx.last_kernel_ms())
     barrier()
     elapsed = time.perf_counter() - t0
+    my_kernel_ms = float(np.mean(kernel_ms))
+    per_rank_ms = [my_kernel_ms]
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, my_kernel_ms], device=comm_device, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        elapsed = max(float(e[0].item()) for e in every)  # MAX over ranks
+        per_rank_ms = [float(e[1].item()) for e in every]
 
     info = ctx.info()
     phase = ctx.phase_cycles()
     if rank == 0:
-        total_pairs = n_pairs * world * args.steps
-        value = total_pairs / elapsed
-        k_s = float(np.mean(kernel_ms)) / 1e3
+        if args.dump_records and merged is not None:
+            np.save(args.dump_records, merged)
+        value = n_total * args.steps / elapsed
+        k_s = my_kernel_ms / 1e3
         bytes_per_pair_site = 8 * pm.K + 0.25  # beta row written + read once, + 2 genotype bits
-        algo_bytes = n_pairs * pm.S * bytes_per_pair_site
+        algo_bytes = n_mine * pm.S * bytes_per_pair_site  # the launch this rank times: its own shard
         achieved = algo_bytes / k_s
+        traffic = measured_traffic(workload_key, ctx.last_beta_stride())
         out = {
-            "metric": "haplotype-pairs decoded/sec (whole node) + GB/s vs HBM roofline, 69-state HMM",
+            "metric": METRIC,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.haps} haplotypes x {args.sites} sites, K={pm.K}, all "
-                                   f"{n_pairs} pairs per GPU, FastSMC-mode IBD + posterior-mean/MAP ages, no hashing",
+            "config": {"workload": desc,
                        "pair_sites_per_s": value * pm.S, "ibd_records_per_step": n_rec,
                        "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
                        "chunk_sites": info["chunk_sites"], "chunks_per_window": info["max_chunks"],
-                       "beta_stride": ctx.last_beta_stride(),
+                       "beta_stride": ctx.last_beta_stride(), "kernel_member": ctx.last_kernel(),
+                       "lib_hash": lib_hash(),
+                       **({"kernel_ms_per_rank": per_rank_ms,
+                           "imbalance_max_over_mean": max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms))}
+                          if world > 1 else {}),
                        **({"DIAGNOSTIC_same_row": True} if args.diag_same_row else {}),
                        **({"phase_cycles": [int(x) for x in phase]} if phase.any() else {})},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": measured_traffic(args.haps, args.sites, pm.K, ctx.last_beta_stride()),
+                         "frac": achieved / HBM_PEAK, "frac_algorithmic": achieved / HBM_PEAK,
+                         "traffic": traffic,
+                         "frac_measured_bytes": (traffic / k_s / HBM_PEAK) if traffic else None,
                          "kernel_ms": 1e3 * k_s, "algorithmic_bytes_per_launch": algo_bytes},
         }
+        if scaling == "strong" and world > 1:
+            ref = committed_measurement("r02_c3_n1.json")
+            if ref and ref.get("workload_key") == workload_key:
+                out["config"]["n1_pairs_per_s_same_worklist"] = ref["value"]
+                out["config"]["speedup_vs_n1"] = value / ref["value"]
         if args.cpu_pairs != 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(pm, haps, args.cpu_pairs, pairs)
         else:

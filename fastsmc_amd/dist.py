@@ -16,6 +16,59 @@ def shard_pair_range(n_pairs: int, rank: int, world: int, batch: int = 64) -> tu
     return min(lo_b * batch, n_pairs), min(hi_b * batch, n_pairs)
 
 
+def shard_groups_by_weight(weights, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous shard [lo, hi) of a list of work-list groups such that every rank gets (as nearly as whole groups
+    allow) the same total weight -- the weight of a group is its pair-sites, pairs x decode-window length, so that
+    hashing-mode lists with windows of 320...5504 sites balance as well as whole-sequence lists.
+    Shard r ends at the first group boundary whose prefix weight reaches total * (r + 1) / world (the reference's
+    own range rule, HMM.cpp:319-321, applied to weight instead of pair count)."""
+    w = np.asarray(weights, dtype=np.float64)
+    if w.size == 0:
+        return 0, 0
+    prefix = np.concatenate([[0.0], np.cumsum(w)])
+    total = prefix[-1]
+
+    def cut(r: int) -> int:
+        if r <= 0:
+            return 0
+        if r >= world:
+            return int(w.size)
+        return int(np.searchsorted(prefix, total * r / world, side="left"))
+
+    return cut(rank), cut(rank + 1)
+
+
+def all_pairs_at(index: np.ndarray) -> np.ndarray:
+    """Rows (hapA, hapB) of the pairs with the given ordinals in HMM::decodeAll's enumeration (HMM.cpp:325-357):
+    individual i contributes the 4*i cross pairs with every j < i -- (jHap, iHap) = (1,1), (2,1), (1,2), (2,2), the
+    lower-numbered individual first -- and then its own two haplotypes, so its block starts at ordinal 2*i*i - i."""
+    x = np.asarray(index, dtype=np.int64)
+    i = ((1.0 + np.sqrt(1.0 + 8.0 * x.astype(np.float64))) / 4.0).astype(np.int64)
+    i = np.where(2 * i * i - i > x, i - 1, i)  # guard the float square root at block boundaries
+    i = np.where(2 * (i + 1) * (i + 1) - (i + 1) <= x, i + 1, i)
+    r = x - (2 * i * i - i)
+    within = r == 4 * i
+    j = np.where(within, i, r // 4)
+    c = r % 4
+    hap_a = np.where(within, 2 * i, 2 * j + (c % 2))
+    hap_b = np.where(within, 2 * i + 1, 2 * i + (c // 2))
+    return np.stack([hap_a, hap_b], axis=1).astype(np.uint32)
+
+
+def sample_pair_ordinals(n_individuals: int, n_pairs: int, seed: int) -> np.ndarray:
+    """A fixed, seeded sub-list of the all-pairs enumeration, in enumeration order (sorted ordinals)."""
+    total = 2 * n_individuals * n_individuals - n_individuals
+    if n_pairs >= total:
+        return np.arange(total, dtype=np.int64)
+    rng = np.random.default_rng(seed)
+    # distinct ordinals without materialising the whole range: draw with a margin, keep the first n_pairs distinct
+    got = np.unique(rng.integers(0, total, size=int(n_pairs * 1.05) + 1024, dtype=np.int64))
+    while got.size < n_pairs:
+        got = np.unique(np.concatenate([got, rng.integers(0, total, size=n_pairs, dtype=np.int64)]))
+    keep = np.sort(rng.permutation(got.size)[:n_pairs])
+    return got[keep]
+
+
 def gather_ibd_records(rec: np.ndarray, pair_offset: int, dist, rank: int, world: int, device="cpu"):
     """Gather every rank's IBD records (structured array with a ``pair`` field holding *local* pair indices) to
     rank 0: all_gather of counts, then gather of padded byte payloads.  Returns (total_count, records_or_None);

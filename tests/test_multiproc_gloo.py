@@ -76,3 +76,74 @@ def test_shard_batch_ranges_tile_the_job():
             assert edges[0][0] == 0 and edges[-1][1] == n_pairs
             assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
             assert all(lo % 32 == 0 for lo, _ in edges)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N (strong scaling of one sharded work list): the exact sharding + gather code path, world 2, gloo
+
+def test_all_pairs_at_matches_the_enumeration():
+    import bench
+    from fastsmc_amd.dist import all_pairs_at, sample_pair_ordinals
+
+    full = bench.all_pairs(37)  # HMM::decodeAll order (HMM.cpp:325-357)
+    np.testing.assert_array_equal(all_pairs_at(np.arange(full.shape[0])), full)
+    o = sample_pair_ordinals(37, 500, seed=3)
+    assert o.size == 500 and np.all(np.diff(o) > 0) and o[-1] < full.shape[0]
+    np.testing.assert_array_equal(sample_pair_ordinals(37, 500, seed=3), o)  # seeded: every rank draws the same list
+    assert sample_pair_ordinals(5, 10 ** 6, seed=1).size == 45  # more than exist: the whole enumeration
+
+
+def test_weight_shards_tile_the_groups_and_balance():
+    from fastsmc_amd.dist import shard_groups_by_weight
+
+    rng = np.random.default_rng(0)
+    for n_groups, world in ((1, 2), (7, 2), (1000, 8), (16384, 8), (5, 8)):
+        for w in (np.ones(n_groups), rng.integers(320, 5504, size=n_groups) * 32.0):  # whole-sequence / hashing windows
+            edges = [shard_groups_by_weight(w, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n_groups
+            assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(edges, edges[1:]))
+            if n_groups >= 100 * world:
+                tot = [w[lo:hi].sum() for lo, hi in edges]
+                assert max(tot) / (sum(tot) / world) < 1.02
+
+
+def _strong_worker(rank, world, port, n_ind, n_list, S, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastsmc_amd.dist import all_pairs_at, sample_pair_ordinals, shard_groups_by_weight
+
+    ordinals = sample_pair_ordinals(n_ind, n_list, 20260)
+    groups = capi.whole_sequence_groups(ordinals.size, S, batch=64)
+    weights = groups["n_pairs"].astype(np.float64) * (groups["to"] - groups["from"])
+    g_lo, g_hi = shard_groups_by_weight(weights, rank, world)
+    lo = int(groups["first_pair"][g_lo]) if g_lo < groups.size else ordinals.size
+    hi = int(groups["first_pair"][g_hi]) if g_hi < groups.size else ordinals.size
+    pairs = all_pairs_at(ordinals[lo:hi])
+    assert pairs.shape[0] == hi - lo and (lo % 64 == 0)
+    rec = _fake_records(lo, hi, seed=7 + lo)  # stands in for the decode of this shard (local pair indices)
+    total, merged = gather_ibd_records(rec, lo, dist, rank, world)
+    if rank == 0:
+        np.save(out_path, merged)
+        np.save(out_path + ".edges.npy", np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_list_world_size_2(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n_ind, n_list, S, world = 30, 1000, 640, 2
+    out = str(tmp_path / "merged.npy")
+    mp.spawn(_strong_worker, args=(world, port, n_ind, n_list, S, out), nprocs=world, join=True)
+    merged = np.load(out)
+    lo0, hi0 = np.load(out + ".edges.npy")
+    assert lo0 == 0 and hi0 % 64 == 0 and abs(hi0 - n_list / 2) <= 64  # equal weight: half the list, whole groups
+    want = []
+    for lo, hi in ((0, int(hi0)), (int(hi0), n_list)):
+        rec = _fake_records(lo, hi, seed=7 + lo)
+        rec["pair"] += np.uint32(lo)
+        want.append(rec)
+    want = np.concatenate(want)
+    assert np.array_equal(merged, want) and np.all(np.diff(merged["pair"].astype(np.int64)) >= 0)
