@@ -239,11 +239,16 @@ class Context:
         self._check(self._L.fsmc_decode_per_pair(self._h, model._h, _p(et), _p(mean), _p(mp)))
         return mean, mp
 
-    def decode_sums(self, model: "Model", major_minor: bool = False, sums: bool = True):
-        """augmentSumOverPairs for the resident work list: arrays [S][K] (sum, and 00/01/11 when asked)."""
+    def decode_sums(self, model: "Model", major_minor: bool = False, sums: bool = True, into=None):
+        """augmentSumOverPairs for the resident work list: arrays [S][K] (sum, and 00/01/11 when asked).  ``into`` =
+        (sum, [s00, s01, s11]) of an earlier call continues that accumulation (sumOverPairs += ..., HMM.cpp:1073)."""
         shape = (model.S, model.K)
-        s = np.zeros(shape, np.float32) if sums else None
-        mm = [np.zeros(shape, np.float32) for _ in range(3)] if major_minor else [None, None, None]
+        if into is not None:
+            s, mm = into
+            mm = list(mm) if major_minor else [None, None, None]
+        else:
+            s = np.zeros(shape, np.float32) if sums else None
+            mm = [np.zeros(shape, np.float32) for _ in range(3)] if major_minor else [None, None, None]
         self._check(self._L.fsmc_decode_sums(self._h, model._h, _p(s), _p(mm[0]), _p(mm[1]), _p(mm[2])))
         return s, mm
 

@@ -22,19 +22,20 @@ using namespace fsmc;
 
 namespace fsmc
 {
-// Sum of the per-wave accumulator planes in slot order (fixed order => reproducible fp32 result).
-__global__ void reduce_planes_kernel(const float* __restrict__ planes, float* __restrict__ out, size_t n, int nSlots,
-                                     size_t slotStride)
+// acc[i] = (((acc[i] + plane_0[i]) + plane_1[i]) + ...): the per-batch sums of one launch are added to the running
+// accumulator one batch after the other, the order of sumOverPairs(pos, k) += sum in HMM::augmentSumOverPairs
+// (HMM.cpp:1054-1073) -- the same fp32 additions in the same order, hence the same bits.
+__global__ void add_planes_in_order_kernel(const float* __restrict__ planes, float* __restrict__ acc, size_t n,
+                                           int nPlanes, size_t planeStride)
 {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int sl = 0; sl < nSlots; ++sl) {
-      s = s + planes[(size_t)sl * slotStride + i];
+    float s = acc[i];
+    for (int sl = 0; sl < nPlanes; ++sl) {
+      s = s + planes[(size_t)sl * planeStride + i];
     }
-    out[i] = s;
+    acc[i] = s;
   }
 }
-
 } // namespace fsmc
 
 namespace
@@ -104,6 +105,33 @@ struct fsmc_model {
 
 namespace
 {
+
+// Two copies of the HIP runtime in one process (e.g. this library linked against /opt/rocm and a PyTorch wheel that
+// bundles its own libamdhip64, loaded in that order) share the device but not their state: kernels built for one
+// wave per SIMD then fail to launch with an opaque "unknown error" from the occupancy query.  Look at the mapped
+// files and say so instead.  Returns the paths of the distinct runtimes found.
+std::vector<std::string> mappedHipRuntimes()
+{
+  std::vector<std::string> found;
+  if (FILE* f = std::fopen("/proc/self/maps", "r")) {
+    char line[4096];
+    while (std::fgets(line, sizeof(line), f)) {
+      const char* slash = std::strchr(line, '/');
+      if (!slash || !std::strstr(slash, "libamdhip64.so")) {
+        continue;
+      }
+      std::string path(slash);
+      while (!path.empty() && (path.back() == '\n' || path.back() == ' ')) {
+        path.pop_back();
+      }
+      if (std::find(found.begin(), found.end(), path) == found.end()) {
+        found.push_back(path);
+      }
+    }
+    std::fclose(f);
+  }
+  return found;
+}
 
 int fail(fsmc_ctx* ctx, int code, const std::string& msg)
 {
@@ -453,6 +481,18 @@ int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
     return fail(nullptr, FSMC_EINVAL, "out is null");
   }
   *out = nullptr;
+  {
+    const std::vector<std::string> rts = mappedHipRuntimes();
+    if (rts.size() > 1) {
+      std::string msg = "two HIP runtimes are loaded in this process (";
+      for (size_t i = 0; i < rts.size(); ++i) {
+        msg += (i ? ", " : "") + rts[i];
+      }
+      msg += "): load one libamdhip64 only -- e.g. import torch before this library so that both resolve to the "
+             "copy torch bundles, or link both against the same ROCm";
+      return fail(nullptr, FSMC_ENODEVICE, msg);
+    }
+  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -1062,36 +1102,54 @@ int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sum
   if (rc != FSMC_OK) {
     return rc;
   }
+  // One launch decodes up to `slots` groups (one per wave; slots = resident waves, fewer if the planes would not fit)
+  // and leaves each group's batch sums in its own plane; add_planes_in_order_kernel then adds the planes to the
+  // accumulator in group order.  The accumulator starts from the caller's arrays, so that several calls (flushes)
+  // continue the same sequential sum.
   const size_t plane = (size_t)m->S * m->K;
+  const int nP = mm ? 4 : 1; // planes per group: the sum, or the sum and its 00 / 01 / 11 split
   const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.25 * (double)ctx->hbmBytes);
   size_t slots = (size_t)plan.slots;
   slots = std::max<size_t>(1, std::min<size_t>(slots, limit / (4 * plane * sizeof(float))));
+  if (const char* cap = std::getenv("FSMC_DIAG_SUMS_SLOTS")) { // tests: force many launches on a small problem
+    const long v = std::atol(cap);
+    if (v >= 1 && (size_t)v < slots) {
+      slots = (size_t)v;
+    }
+  }
   rc = ensure(ctx, ctx->out, (slots + 1) * 4 * plane * sizeof(float));
   if (rc != FSMC_OK) {
     return rc;
   }
-  FSMC_HIP(ctx, hipMemsetAsync(ctx->out.p, 0, (slots + 1) * 4 * plane * sizeof(float), ctx->stream));
+  float* const acc = (float*)ctx->out.p + slots * 4 * plane;
+  float* dst[4] = {sums, sums00, sums01, sums11};
+  for (int q = 0; q < 4; ++q) {
+    if (dst[q]) {
+      FSMC_HIP(ctx, hipMemcpyAsync(acc + (size_t)q * plane, dst[q], plane * sizeof(float), hipMemcpyHostToDevice,
+                                   ctx->stream));
+    }
+  }
   KParams p;
   fillParams(ctx, m, plan, (sums ? FSMC_WANT_SUMS : 0u) | (mm ? FSMC_WANT_MAJOR_MINOR_SUMS : 0u), p);
   p.sums = (float*)ctx->out.p;
   p.sumsPlane = plane;
-  rc = launch(ctx, fn, p, (int)slots);
-  if (rc != FSMC_OK) {
-    return rc;
+  (void)nP;
+  for (size_t base = 0; base < ctx->nGroups; base += slots) {
+    const size_t n = std::min(slots, ctx->nGroups - base);
+    p.groupBase = (int)base;
+    rc = launch(ctx, fn, p, (int)n);
+    if (rc != FSMC_OK) {
+      return rc;
+    }
+    // (planes the launch did not ask for hold stale values: they are added to accumulator planes nobody reads)
+    hipLaunchKernelGGL(add_planes_in_order_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const float*)ctx->out.p, acc,
+                       4 * plane, (int)n, 4 * plane);
+    FSMC_HIP(ctx, hipGetLastError());
   }
-  float* reduced = (float*)ctx->out.p + slots * 4 * plane;
-  hipLaunchKernelGGL(reduce_planes_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const float*)ctx->out.p, reduced,
-                     4 * plane, (int)slots, 4 * plane);
-  FSMC_HIP(ctx, hipGetLastError());
   FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<float> host(4 * plane);
-  FSMC_HIP(ctx, hipMemcpy(host.data(), reduced, 4 * plane * sizeof(float), hipMemcpyDeviceToHost));
-  float* dst[4] = {sums, sums00, sums01, sums11};
   for (int q = 0; q < 4; ++q) {
     if (dst[q]) {
-      for (size_t i = 0; i < plane; ++i) {
-        dst[q][i] += host[(size_t)q * plane + i]; // accumulates, like sumOverPairs(pos,k) += sum (HMM.cpp:1073)
-      }
+      FSMC_HIP(ctx, hipMemcpy(dst[q], acc + (size_t)q * plane, plane * sizeof(float), hipMemcpyDeviceToHost));
     }
   }
   return FSMC_OK;

@@ -47,6 +47,7 @@ struct KParams {
   int S;       // sites
   int W;       // 64-bit words per haplotype row
   int nGroups;
+  int groupBase; // kModeSums: this launch decodes groups groupBase .. groupBase + gridDim.x - 1, one per wave
   int chunk;   // sites per chunk (C)
   int chunkRows; // rows of the chunk buffer: C, or (C+1)/2 with beta stride 2
   int maxChunks;
@@ -81,7 +82,7 @@ struct KParams {
   int* ppMap;                 // kModePerPair: [nPairs][S]
   const float* expCoal;       // kModePerPair: [KP]
   unsigned long long* phaseCycles; // diagnostic builds (-DFSMC_PHASE_STAMPS): [0] pass B, [1] rebuild, [2] alpha sweep, [3] groups
-  float* sums;                // kModeSums: per-slot accumulators [slots][S][K] (+ 00/01/11 planes)
+  float* sums;                // kModeSums: one plane [S][K] (x4 with the 00/01/11 sums) per wave of the launch
   size_t sumsPlane;           // floats per plane per slot
 };
 
@@ -1207,9 +1208,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
   for (unsigned round = 0;; ++round) {
     unsigned g = 0;
     if (MODE == kModeSums) {
-      // each resident wave owns an accumulator plane and takes groups slot, slot + nSlots, ... in order, so the
-      // order of float additions is fixed from run to run
-      g = blockIdx.x + round * gridDim.x;
+      // one group per wave and launch: wave i writes the batch sums of group groupBase + i into plane i, and the host
+      // adds the planes to the accumulator one after the other -- the reference's order, batch by batch
+      // (HMM.cpp:1054-1073)
+      g = round == 0 ? (unsigned)p.groupBase + blockIdx.x : (unsigned)p.nGroups;
     } else {
       if (lane == 0) {
         g = atomicAdd(&p.counters[0], 1u);
@@ -1827,11 +1829,11 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
               }
             }
             float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + kk;
-            if (p.flags & FSMC_WANT_SUMS) acc[0] += s;
+            if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
             if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-              acc[p.sumsPlane] += s00;
-              acc[2 * p.sumsPlane] += s01;
-              acc[3 * p.sumsPlane] += s11;
+              acc[p.sumsPlane] = s00;
+              acc[2 * p.sumsPlane] = s01;
+              acc[3 * p.sumsPlane] = s11;
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

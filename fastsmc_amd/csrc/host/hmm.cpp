@@ -552,7 +552,24 @@ void HMM::closeBatch(bool last)
     mPairs.resize(mBatchBegin);
     return;
   }
-  for (size_t off = 0; off < n; off += 64) {
+  // Lane packing.  A wavefront decodes a group of up to 64 pairs that share a window.  Outside hashing mode every
+  // window is the whole sequence and nothing a pair's output depends on involves the other pairs of its batch, so a
+  // batch smaller than a wavefront (the FastSMC default is 32) is appended to the previous group while that has
+  // free lanes: same records, same order (they are ordered by pair), full waves.  Not for the sums over pairs --
+  // there the reference adds batch by batch (HMM.cpp:1054-1073) and a group stays one batch.
+  const bool wholeSequence = !(mParams.FastSMC && mParams.hashing);
+  const bool packLanes = wholeSequence && !mParams.doPosteriorSums && !mParams.doMajorMinorPosteriorSums;
+  size_t off = 0;
+  if (packLanes && !mGroups.empty()) {
+    fsmc_group& g = mGroups.back();
+    if (g.first_pair + g.n_pairs == mBatchBegin && g.n_pairs < 64 && g.from == from && g.to == to &&
+        g.scan_from == scanFrom && g.scan_to == scanTo) {
+      const size_t take = std::min<size_t>(64 - g.n_pairs, n);
+      g.n_pairs += static_cast<uint32_t>(take);
+      off = take;
+    }
+  }
+  for (; off < n; off += 64) {
     fsmc_group g{};
     g.first_pair = static_cast<uint32_t>(mBatchBegin + off);
     g.n_pairs = static_cast<uint32_t>(std::min<size_t>(64, n - off));

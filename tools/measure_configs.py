@@ -145,6 +145,59 @@ def hashing():
                       "all_pairs": n_hap * (n_hap - 1) // 2 + 0}))
 
 
+def run_c2(n_hap=1000, n_sites=50000):
+    """The PRODUCT path at the bench's size: FastSMC(params).run() end to end on C2 files -- read .hap.gz / .samples /
+    .map / .decodingQuantities.gz, enumerate all pairs in batches of 32 (the reference default), decode, format and
+    write the .ibd.gz -- next to the decode-only rate of bench.py."""
+    import hashlib
+
+    from oracle import oracle as O
+
+    tables = synth.make_model_tables(69)
+    haps = synth.make_haps(n_hap, n_sites, seed=1234)
+    with tempfile.TemporaryDirectory() as d:
+        root = os.path.join(d, "syn")
+        t0 = time.perf_counter()
+        synth.write_haps_files(root, haps)
+        gen = (haps.cm / 100.0).astype(np.float32)
+        used = np.unique(np.concatenate([[0.0], O.step_rows(tables.keys, gen)[1][1:]]))
+        t = copy.copy(tables)
+        sel = np.nonzero(np.isin(t.keys, used.astype(np.float32)))[0]
+        t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
+        synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
+        t_write = time.perf_counter() - t0
+        p = api.DecodingParams()
+        p.inFileRoot = root
+        p.decodingQuantFile = root + ".decodingQuantities.gz"
+        p.outFileRoot = os.path.join(d, "out")
+        p.decodingModeString = "array"
+        p.foldData = True
+        p.usingCSFS = True
+        p.batchSize = 32
+        p.hashing = False
+        p.FastSMC = True
+        p.BIN_OUT = False
+        p.outputIbdSegmentLength = True
+        p.time = 50
+        p.noConditionalAgeEstimates = True
+        p.doPerPairMAP = True
+        p.doPerPairPosteriorMean = True
+        p.useKnownSeed = True
+        assert p.validateParamsFastSMC()
+        t0 = time.perf_counter()
+        f = api.FastSMC(p)
+        t_init = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        f.run()
+        t_run = time.perf_counter() - t0
+        txt = gzip.open(p.outFileRoot + ".1.1.FastSMC.ibd.gz", "rb").read()
+    n_pairs = n_hap * (n_hap - 1) // 2
+    print(json.dumps({"config": "run_c2_product_path", "haplotypes": n_hap, "sites": n_sites, "K": 69,
+                      "batchSize": 32, "pairs": n_pairs, "write_inputs_s": t_write, "construct_s": t_init,
+                      "run_s": t_run, "pairs_per_s_run": n_pairs / t_run, "ibd_lines": txt.count(b"\n"),
+                      "ibd_text_md5": hashlib.md5(txt).hexdigest()}))
+
+
 def short_windows():
     """The hashing regime (C5): batches of 32 pairs, each with its own short decode window (384-site median, as the
     C1 hashing run of SURVEY.md §0.9) -- pair-sites/s of the IBD decode alone."""
@@ -180,4 +233,4 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
         {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "hashing": hashing,
-         "short": short_windows}[w]()
+         "short": short_windows, "run_c2": run_c2}[w]()
