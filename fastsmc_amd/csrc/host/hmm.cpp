@@ -720,45 +720,60 @@ void HMM::openIbdFile(int jobs, int jobInd)
   }
 }
 
-void HMM::decodeAll(int jobs, int jobInd)
+template <typename Fn> void HMM::forEachPairOfJob(int jobs, int jobInd, bool shardOnly, Fn&& fn) const
 {
-  resetDecoding();
   const unsigned long long N = mData.numIndividuals();
-  if (mParams.FastSMC) {
-    openIbdFile(jobs, jobInd);
-    if (mParams.hashing) {
-      return; // pairs arrive through decodeFromHashing
-    }
-  }
   // pair range of this job (HMM.cpp:310-321)
   const unsigned long long totPairs = mParams.withinOnly ? N : 2 * N * N - N;
   const unsigned long long pairsStart = totPairs * static_cast<unsigned long long>(jobInd - 1) / jobs;
   const unsigned long long pairsEnd = totPairs * static_cast<unsigned long long>(jobInd) / jobs;
-  // this device's share of the job: whole batches, contiguous (setShard)
-  const auto B = static_cast<unsigned long long>(mBatchSize);
-  const auto [batchLo, batchHi] = shardBatchRange((pairsEnd - pairsStart + B - 1) / B);
-  const unsigned long long shardStart = std::min(pairsEnd, pairsStart + batchLo * B);
-  const unsigned long long shardEnd = std::min(pairsEnd, pairsStart + batchHi * B);
+  unsigned long long lo = pairsStart, hi = pairsEnd;
+  if (shardOnly) {
+    // this device's share of the job: whole batches, contiguous (setShard)
+    const auto B = static_cast<unsigned long long>(mBatchSize);
+    const auto [batchLo, batchHi] = shardBatchRange((pairsEnd - pairsStart + B - 1) / B);
+    lo = std::min(pairsEnd, pairsStart + batchLo * B);
+    hi = std::min(pairsEnd, pairsStart + batchHi * B);
+  }
   unsigned long long pairs = 0;
   for (unsigned i = 0; i < N; i++) {
     if (!mParams.withinOnly) {
       for (unsigned j = 0; j < i; j++) {
         for (int iHap = 1; iHap <= 2; iHap++) {
           for (int jHap = 1; jHap <= 2; jHap++) {
-            if (shardStart <= pairs && pairs < shardEnd) {
+            if (lo <= pairs && pairs < hi) {
               // makePairObs(jHap, j, iHap, i): the lower-numbered individual is the record's first id
-              queuePair(static_cast<unsigned>(dipToHapId(j, jHap)), static_cast<unsigned>(dipToHapId(i, iHap)));
+              fn(static_cast<unsigned>(dipToHapId(j, jHap)), static_cast<unsigned>(dipToHapId(i, iHap)));
             }
             pairs++;
           }
         }
       }
     }
-    if (shardStart <= pairs && pairs < shardEnd) {
-      queuePair(static_cast<unsigned>(dipToHapId(i, 1)), static_cast<unsigned>(dipToHapId(i, 2)));
+    if (lo <= pairs && pairs < hi) {
+      fn(static_cast<unsigned>(dipToHapId(i, 1)), static_cast<unsigned>(dipToHapId(i, 2)));
     }
     pairs++;
   }
+}
+
+std::vector<std::pair<unsigned, unsigned>> HMM::pairsOfJob(int jobs, int jobInd) const
+{
+  std::vector<std::pair<unsigned, unsigned>> out;
+  forEachPairOfJob(jobs, jobInd, false, [&](unsigned a, unsigned b) { out.emplace_back(a, b); });
+  return out;
+}
+
+void HMM::decodeAll(int jobs, int jobInd)
+{
+  resetDecoding();
+  if (mParams.FastSMC) {
+    openIbdFile(jobs, jobInd);
+    if (mParams.hashing) {
+      return; // pairs arrive through decodeFromHashing
+    }
+  }
+  forEachPairOfJob(jobs, jobInd, true, [&](unsigned a, unsigned b) { queuePair(a, b); });
   finishDecoding();
 }
 

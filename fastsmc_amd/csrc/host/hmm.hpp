@@ -84,6 +84,8 @@ public:
   HMM& operator=(const HMM&) = delete;
 
   void decodeAll(int jobs, int jobInd);                                          // HMM.cpp:283-381
+  // the haplotype-row pairs decodeAll(jobs, jobInd) decodes, in its order (tests; no decoding)
+  std::vector<std::pair<unsigned, unsigned>> pairsOfJob(int jobs, int jobInd) const;
   void decodePair(unsigned i, unsigned j);                                       // HMM.cpp:413-440
   void decodePairs(const std::vector<unsigned>& A, const std::vector<unsigned>& B); // HMM.cpp:403-411
   void decodeHapPair(unsigned long i, unsigned long j);                          // HMM.cpp:442-458
@@ -154,6 +156,7 @@ private:
   void prepareEmissions(); // HMM.cpp:159-256
   void prepareModel();
   void ensureEngine();
+  template <typename Fn> void forEachPairOfJob(int jobs, int jobInd, bool shardOnly, Fn&& fn) const;
   void queuePair(unsigned hapRowA, unsigned hapRowB);
   void closeBatch(bool last);
   void flush();

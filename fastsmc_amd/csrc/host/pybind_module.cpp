@@ -349,6 +349,8 @@ PYBIND11_MODULE(_pyasmc, m)
       .def("decode", py::overload_cast<const PairObservations&>(&HMM::decode))
       .def("decode", py::overload_cast<const PairObservations&, unsigned, unsigned>(&HMM::decode))
       .def("decodeAll", &HMM::decodeAll, "jobs"_a, "jobInd"_a)
+      .def("pairsOfJob", &HMM::pairsOfJob, "jobs"_a, "jobInd"_a,
+           "haplotype-row pairs decodeAll(jobs, jobInd) decodes, in its order (no decoding)")
       .def("getDecodingReturnValues", &HMM::getDecodingReturnValues, py::return_value_policy::reference_internal)
       .def("getDecodePairsReturnStruct", &HMM::getDecodePairsReturnStruct, py::return_value_policy::reference_internal)
       .def("decodePair", &HMM::decodePair)
