@@ -1064,6 +1064,27 @@ __device__ __forceinline__ gf32x4_p rowSlot(const gchar_p base, const int k4, co
 {
   return (gf32x4_p)(base + (size_t)k4 * (kWave * sizeof(float4)) + laneOff);
 }
+// LDS-DMA of 16 bytes per lane (lane i lands at lds + 16*i) as inline asm, for the two-slot rings.  Through the
+// builtin the compiler knows that LDS is being written and -- the two slots of a ring being one array -- guards the
+// reads of the OTHER slot with a vmcnt(0), i.e. waits for the request that was just issued for the next site.  As
+// asm the request is opaque (a "memory" clobber keeps LDS accesses from moving across it) and is covered by the
+// explicit vmcnt waits of the callers.  M0 carries the LDS address; the compiler re-initialises M0 before every use
+// of its own, and the clobber tells it that this statement changes it.
+#if defined(__clang__)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#endif
+__device__ __forceinline__ void dmaToLds(const gf32x4_p src, const void* ldsDst)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lds = (unsigned)(unsigned long long)(const char __attribute__((address_space(3)))*)ldsDst;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+#endif
+}
+#if defined(__clang__)
+#pragma clang diagnostic pop
+#endif
+
 template <int KT, int KA>
 __device__ __forceinline__ void store_vec(const int K, float4* row, const unsigned laneOff, const float (&v)[KA])
 {
@@ -1289,10 +1310,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
       for (int i = 0; i < NL; ++i) {
         const int idx = lane + i * kWave;
         if (idx < NC * E4) {
-#if defined(__HIP_DEVICE_COMPILE__)
-          __builtin_amdgcn_global_load_lds((gf32x4_p)(src + (size_t)i * (kWave * sizeof(float4)) + laneOff),
-                                           &emisLds[q & 1][i * kWave], 16, 0, 0);
-#endif
+          dmaToLds((gf32x4_p)(src + (size_t)i * (kWave * sizeof(float4)) + laneOff), &emisLds[q & 1][i * kWave]);
         }
       }
     };
@@ -1308,6 +1326,10 @@ __global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
         const int idx = blk * kWave + lane;
         rowVec = p.stepRow[idx < p.S ? idx : p.S - 1];
         rowBlk = blk;
+        // waited for here, once per 64 sites: otherwise the compiler, which cannot tell at the v_readlane below
+        // whether this load is the pending one, waits for vmcnt(0) at EVERY site -- right behind the emission-row
+        // request that was just issued
+        waitVm0();
       }
       return __builtin_amdgcn_readlane(rowVec, site & (kWave - 1));
     };

@@ -23,6 +23,8 @@
 // forward term's B[K-1]*alphaC[K] = B*0 = 0 are what the reference writes explicitly (HMM.cpp:986-1005, 823-826).
 #pragma once
 
+#include <type_traits>
+
 #include "fsmc_kernels.h"
 
 namespace fsmc
@@ -33,6 +35,13 @@ namespace fsmc
 // 512 (the rest in AGPRs, no scratch) and measured 14 % faster -- the LDS ring allows only five waves per CU anyway.
 #ifndef FSMC_Q4_MINBLOCKS
 #define FSMC_Q4_MINBLOCKS(KQ) ((KQ) == 64 ? 1 : 2)
+#endif
+// The four phases of a recurrence as a loop (one copy of the body, a taken branch per phase) or unrolled (four copies,
+// no branch: a taken branch costs an in-order wave ~100 cycles, and a step has ~24 of them).
+#if defined(FSMC_Q4_ROLLED_PHASES)
+#define FSMC_Q4_PHASE_LOOP _Pragma("nounroll")
+#else
+#define FSMC_Q4_PHASE_LOOP _Pragma("unroll")
 #endif
 constexpr int kQ4MaxStates = 64;          // largest KQ: 4 * 64 = 256 states
 constexpr int kQuadUp = 0xF9;             // quad_perm [1,2,3,3]: lane q reads lane q+1
@@ -59,7 +68,7 @@ __device__ __forceinline__ float f4at(const float4& q, const int i)
 template <int KQ> __device__ __forceinline__ float quadOrderedSum(const float (&v)[KQ], const int qd)
 {
   float sOut = 0.f;
-#pragma nounroll
+FSMC_Q4_PHASE_LOOP
   for (int ph = 0; ph < 4; ++ph) {
     const float c = quadMove<kQuadDn>(sOut);
     if (qd == ph) {
@@ -110,7 +119,7 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[KQ], float (&w)[KQ], flo
       rrv[j4] = rRR[j4];
     }
     float tLow = 0.f, buLow = 0.f; // T and BU of this lane's lowest state, for the quarter below
-#pragma nounroll
+FSMC_Q4_PHASE_LOOP
     for (int ph = 3; ph >= 0; --ph) {
       const float cT = quadMove<kQuadUp>(tLow);
       const float cB = quadMove<kQuadUp>(buLow);
@@ -146,7 +155,7 @@ __device__ __forceinline__ void beta_step_q4(float (&b)[KQ], float (&w)[KQ], flo
   float blIn = 0.f; // BL of this lane's first state
   {
     float blOut = 0.f;
-#pragma nounroll
+FSMC_Q4_PHASE_LOOP
     for (int ph = 0; ph < 4; ++ph) {
       const float c = quadMove<kQuadDn>(blOut);
       if (qd == ph) {
@@ -212,7 +221,7 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[KQ], float (&w)[KQ], fl
   // suffix sums one slot down: w[j] = alphaC of the state after j (quarter 3 first)
   {
     float cOut = 0.f; // alphaC of this lane's first state
-#pragma nounroll
+FSMC_Q4_PHASE_LOOP
     for (int ph = 3; ph >= 0; --ph) {
       const float c = quadMove<kQuadUp>(cOut);
       if (qd == ph) {
@@ -251,7 +260,7 @@ __device__ __forceinline__ void alpha_step_q4(float (&a)[KQ], float (&w)[KQ], fl
       crv[j4] = rC[j4];
     }
     float auOut = 0.f;
-#pragma nounroll
+FSMC_Q4_PHASE_LOOP
     for (int ph = 0; ph < 4; ++ph) {
       const float c = quadMove<kQuadDn>(auOut);
       if (qd == ph) {
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
                                 4 * lane + 3 < K ? 1.f : 0.f);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
+  waitLgkm0();
   __builtin_amdgcn_wave_barrier();
   const float4* const maskOf = &maskLds[(KQ / 4) * qd];
   const cfloat_p tPi = (cfloat_p)p.pi, tExpT = (cfloat_p)p.expT;
@@ -395,9 +404,7 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
 #pragma unroll
     for (int i = 0; i < (3 * KQ + kWave - 1) / kWave; ++i) {
       if (i * kWave + lane < 3 * KQ) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_global_load_lds(src + i * kWave + lane, &emisLds[site & 1][i * kWave], 16, 0, 0);
-#endif
+        dmaToLds((gf32x4_p)(src + i * kWave + lane), &emisLds[site & 1][i * kWave]); // (see dmaToLds: ring slots)
       }
     }
   };
@@ -414,24 +421,30 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
         const int r = idx / KQ;
         const int off = idx - r * KQ;
         const float4* src = (r == 0 ? rs + kRowD * KQ : r == 1 ? rs + kRowB * KQ : r == 2 ? r2 : r3) + off;
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_global_load_lds(src, &rowLds[site & 1][i * kWave], 16, 0, 0);
-#endif
+        dmaToLds((gf32x4_p)src, &rowLds[site & 1][i * kWave]);
       }
     }
   };
+  // (the waits are the s_waitcnt builtin: the compiler's wait-count pass sees them and adds none of its own for the
+  //  LDS reads of DMA-landed data -- as inline asm it could not, and guarded every such read with a vmcnt(0))
   auto landed = [&]() { // every outstanding DMA (and store) of this wave is done and visible to its LDS reads
-    FSMC_GCN_ASM("s_waitcnt vmcnt(0)" ::: "memory");
+    waitVm0();
     __builtin_amdgcn_wave_barrier();
   };
-  // the same while the 16 row stores issued AFTER the DMA requests may still be in flight (vector memory
-  // operations retire in order, so at most 16 outstanding means the older DMA requests are done)
-  auto landedBeforeRowStores = [&]() {
-    FSMC_GCN_ASM("s_waitcnt vmcnt(16)" ::: "memory");
+  // the same while the N youngest vector-memory operations may still be in flight (they retire in order, so "at most
+  // N outstanding" means every older request is done): N = the KQ/4 row stores / beta-row DMAs issued AFTER the
+  // requests waited for, or the staging requests of the next site issued after the beta row
+  constexpr unsigned kRowOps = KQ / 4;                                            // stores or DMAs of one stored row
+  constexpr unsigned kStageOps = (3 * KQ + kWave - 1) / kWave + (4 * KQ + kWave - 1) / kWave; // stageEmis + stageRows
+  auto landedExceptYoungest = [&](auto n) {
+    constexpr unsigned N = decltype(n)::value;
+    static_assert(N < 64, "vmcnt is a six-bit counter");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15u) | ((N >> 4) << 14));
     __builtin_amdgcn_wave_barrier();
   };
+  auto landedBeforeRowStores = [&]() { landedExceptYoungest(std::integral_constant<unsigned, kRowOps>{}); };
   auto ldsReadsDone = [&]() {
-    FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)" ::: "memory");
+    waitLgkm0();
     __builtin_amdgcn_wave_barrier();
   };
   auto fetchBeta = [&](const float4* row) { // row: wave-uniform address of the stored vector (see store_vec)
@@ -631,13 +644,20 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       landed();
       ldsReadsDone();
-      fetchBeta(chunkbuf);
+      // Requests run one site ahead of their use, each covered by a whole forward step: the rows of site pos+1 are
+      // asked for when site pos opens (their ring slot was last read by site pos-1), the beta row of pos+1 after
+      // the combine of pos (one landing zone).  Vector-memory operations retire in order, so the waits count what
+      // may stay in flight: the beta row (youngest when a site opens), the next site's rows (youngest at the combine).
       stageEmis(lo);
-      if (lo > from) {
-        stageRows(lo, true);
-      }
+      stageRows(lo, true); // (unused at the window's first site; keeps the number of requests per site fixed)
+      fetchBeta(chunkbuf);
       for (int pos = lo; pos < hi; ++pos) {
-        landed(); // rows of this site, its beta row
+        landedExceptYoungest(std::integral_constant<unsigned, kRowOps>{}); // rows of this site
+        const bool stagedNext = pos + 1 < hi;
+        if (stagedNext) {
+          stageEmis(pos + 1);
+          stageRows(pos + 1, true);
+        }
         const int c = obsClass(pos);
         const float4* e = emisOf(pos, c);
         if (pos == from) {
@@ -661,6 +681,11 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
           alpha_step_q4<KQ>(a, w, x, e, rowOf(pos, 0), rowOf(pos, 1), rowOf(pos, 2), rowOf(pos, 3), qd);
         }
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
+        if (stagedNext) {
+          landedExceptYoungest(std::integral_constant<unsigned, kStageOps>{}); // this site's beta row
+        } else {
+          landed();
+        }
 #pragma unroll
         for (int j4 = 0; j4 < (KQ / 4); ++j4) {
           const float4 bv = betaLds[j4 * kWave + lane];
@@ -675,8 +700,6 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
         ldsReadsDone();
         if (pos + 1 < hi) {
           fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
-          stageEmis(pos + 1);
-          stageRows(pos + 1, true);
         }
 
         if (MODE == kModeDump) {

@@ -552,13 +552,14 @@ void HMM::closeBatch(bool last)
     mPairs.resize(mBatchBegin);
     return;
   }
-  // Lane packing.  A wavefront decodes a group of up to 64 pairs that share a window.  Outside hashing mode every
-  // window is the whole sequence and nothing a pair's output depends on involves the other pairs of its batch, so a
-  // batch smaller than a wavefront (the FastSMC default is 32) is appended to the previous group while that has
-  // free lanes: same records, same order (they are ordered by pair), full waves.  Not for the sums over pairs --
-  // there the reference adds batch by batch (HMM.cpp:1054-1073) and a group stays one batch.
-  const bool wholeSequence = !(mParams.FastSMC && mParams.hashing);
-  const bool packLanes = wholeSequence && !mParams.doPosteriorSums && !mParams.doMajorMinorPosteriorSums;
+  // Lane packing.  A wavefront decodes a group of up to 64 pairs that share a decode window and a scan window, and
+  // nothing a pair's output depends on involves the other pairs of its group.  So a batch smaller than a wavefront
+  // (the FastSMC default is 32) is appended to the previous group while that has free lanes and the SAME windows:
+  // same records, same order (they are ordered by pair), fuller waves.  Outside hashing mode every window is the
+  // whole sequence and every group fills up; in hashing mode consecutive batches closed at the same word often share
+  // their union window.  Not for the sums over pairs -- there the reference adds batch by batch (HMM.cpp:1054-1073)
+  // and a group stays one batch.
+  const bool packLanes = !mParams.doPosteriorSums && !mParams.doMajorMinorPosteriorSums;
   size_t off = 0;
   if (packLanes && !mGroups.empty()) {
     fsmc_group& g = mGroups.back();
