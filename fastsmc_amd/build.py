@@ -18,8 +18,8 @@ HIPCC_FLAGS = [
 ]
 
 # family members of the library (csrc/fsmc_instances.h): one translation unit each, compiled in parallel
-KT_MEMBERS = [0, 16, 32, 48, 64, 69, 80]
-Q4_MEMBERS = [32, 48, 64]
+KT_MEMBERS = [0, 16, 32, 48, 64, 69, 80, 96, 112, 128]
+Q4_MEMBERS = [48, 64]
 OBJ_DIR = os.path.join(CSRC, "obj")
 
 

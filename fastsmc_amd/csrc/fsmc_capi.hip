@@ -204,13 +204,13 @@ std::vector<float> padRows(const float* src, size_t rows, int K, int KP)
 using KernelFn = void (*)(const KParams);
 
 // Which member of the lane-per-pair family decodes a model (fsmc_instances.h): 69 for the reference's 69-state
-// models, the padded row length for every other model of at most 80 states, 0 (runtime K) beyond.
+// models, the padded row length for every other model of at most 128 states, 0 (runtime K) beyond.
 int familyMember(const fsmc_model* m)
 {
   if (m->K == 69) {
     return 69;
   }
-  return m->K <= 80 ? m->KP : 0;
+  return (m->K <= 128 && m->KP % kKPad == 0 && m->KP <= 128) ? m->KP : 0;
 }
 
 template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half)
@@ -246,12 +246,12 @@ bool halfAvailable(int mode, const fsmc_model* m)
 }
 
 // The wide-model kernel (four lanes per pair, fsmc_kernels_q4.h): 80 < K <= 256, array mode, IBD, per-pair and dump
-// consumers.  fsmc_model_create pads such a model's rows to KP = 128, 192 or 256 floats = 4 x the states per lane.
+// consumers.  fsmc_model_create pads such a model's rows to KP = 192 or 256 floats = 4 x the states per lane.
 bool quarterLanes(int mode, const fsmc_model* m)
 {
-  return m->K > 80 && m->K <= 4 * kQ4MaxStates && !m->sequence &&
+  return familyMember(m) == 0 && m->K > 69 && m->K <= 4 * kQ4MaxStates && !m->sequence &&
          (mode == kModeIbd || mode == kModeDump || mode == kModePerPair) &&
-         (m->KP == 128 || m->KP == 192 || m->KP == 256);
+         (m->KP == 192 || m->KP == 256);
 }
 
 template <int KQ> KernelFn pickQuarterKernel(int mode, bool track)
@@ -272,8 +272,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
       m->ctx->lastStride = 1;
     }
     m->ctx->lastMember = -(m->KP / 4);
-    return m->KP == 128 ? pickQuarterKernel<32>(mode, track)
-                        : m->KP == 192 ? pickQuarterKernel<48>(mode, track) : pickQuarterKernel<64>(mode, track);
+    return m->KP == 192 ? pickQuarterKernel<48>(mode, track) : pickQuarterKernel<64>(mode, track);
   }
   const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1;
   if (mode == kModeIbd) {
@@ -294,6 +293,12 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
     return pickMember<69>(mode, track, m->sequence, half);
   case 80:
     return pickMember<80>(mode, track, m->sequence, half);
+  case 96:
+    return pickMember<96>(mode, track, m->sequence, half);
+  case 112:
+    return pickMember<112>(mode, track, m->sequence, half);
+  case 128:
+    return pickMember<128>(mode, track, m->sequence, half);
   default:
     return pickMember<0>(mode, track, m->sequence, false);
   }
@@ -677,7 +682,7 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   m->ctx = ctx;
   m->K = d->K;
   m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
-  if (d->K > 80) {
+  if (d->K > 128) {
     // wide models: four lanes per pair hold KP/4 states each (fsmc_kernels_q4.h); the padding states are ghosts
     m->KP = d->K <= 128 ? 128 : d->K <= 192 ? 192 : 256;
   }

@@ -8,8 +8,9 @@
 // Lane-per-pair family (decode_kernel<KT, MODE, TRACK, SEQ, HALF>):
 //   KT = 69               the 69-state models of the reference's decoding-quantities files, no padding
 //   KT = 16, 32, 48, 64, 80   every other model with K <= 80: padded with ghost states to the next member
-//   KT = 0                runtime K (wide models in the modes the four-lanes-per-pair kernel does not have)
-// Four-lanes-per-pair kernel (decode_kernel_q4<KQ, MODE, TRACK>): 80 < K <= 256, KQ = 32, 48, 64 states per lane.
+//   KT = 96, 112, 128     80 < K <= 128: the same kernel with one wave per SIMD (512 registers a lane)
+//   KT = 0                runtime K (128 < K <= 256 in the modes the four-lanes-per-pair kernel does not have)
+// Four-lanes-per-pair kernel (decode_kernel_q4<KQ, MODE, TRACK>): 128 < K <= 256, KQ = 48, 64 states per lane.
 #pragma once
 
 #include "fsmc_kernels.h"
@@ -21,7 +22,7 @@ namespace fsmc
 // beta stride 2 needs three K-vectors in a lane's registers: built for the members it fits
 constexpr bool halfBuilt(const int KT)
 {
-  return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 69;
+  return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 69 || KT == 96 || KT == 112 || KT == 128;
 }
 
 #define FSMC_KT_KERNELS(X, KT)                                                                                         \
@@ -52,8 +53,8 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_DEFINE_Q4(KQ, MODE, TRACK) template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 
 // every member of the library (build.py compiles fsmc_inst.hip once for each entry of these two lists)
-#define FSMC_ALL_KT(Y) Y(0) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80)
-#define FSMC_ALL_Q4(Y) Y(32) Y(48) Y(64)
+#define FSMC_ALL_KT(Y) Y(0) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80) Y(96) Y(112) Y(128)
+#define FSMC_ALL_Q4(Y) Y(48) Y(64)
 
 #if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_Q4)
 #define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)
@@ -63,6 +64,9 @@ FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 32)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 48)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 64)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 69)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 96)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 112)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 128)
 #define FSMC_DECLARE_Q4_MEMBER(KQ) FSMC_Q4_KERNELS(FSMC_DECLARE_Q4, KQ)
 FSMC_ALL_Q4(FSMC_DECLARE_Q4_MEMBER)
 #endif

@@ -1172,8 +1172,14 @@ __device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, c
 // (and of the chunk's last site) are written to HBM; the alpha sweep recomputes the row of an even-offset site
 // from its successor's row (already landed in LDS) with one more beta step.  Half the HBM traffic of the beta
 // stream for half a sweep of extra arithmetic; the floating-point operations of every row are unchanged.
+// Waves per SIMD the register allocation leaves room for: two 256-register waves up to 80 states; the members for 96,
+// 112 and 128 states keep their two or three K-vectors in registers only with the whole 512-entry file (one wave).
+constexpr int minWavesPerSimd(const int KT)
+{
+  return KT > 80 ? 1 : 2;
+}
 template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF>
-__global__ __launch_bounds__(kWave, 2) void decode_kernel(const KParams p)
+__global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(const KParams p)
 {
   static_assert(!HALF || (!SEQ && MODE == kModeIbd), "beta stride 2 is built for the array-mode IBD decode");
   // array mode with a compile-time K: the backward loops are rotated (operand-free step tails overlap the next

@@ -1,8 +1,8 @@
 """Models other than K = 69 against the oracle, all output modes.  K <= 80 runs the lane-per-pair kernel compiled for
-the next family member (16, 32, 48, 64, 80 states; the padding states are ghosts -- K = 2, 5, 16 exactly, 17, 33, 50, 64
-exactly, 65, 70, 80 exactly); 80 < K <= 256 the wide-model kernel (four lanes per pair, 32 / 48 / 64 states per lane,
-ghost-padded -- K = 81, 100, 128 exactly, 130, 192 exactly, 200, 256 exactly), whose sums over pairs still come from the
-runtime-K kernel.  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
+the next family member (16, 32, 48, 64, 80 states with two waves per SIMD, 96, 112, 128 with one; the padding states are
+ghosts -- K = 2, 5, 16 exactly, 17, 33, 50, 64 exactly, 65, 70, 80 exactly, 81, 100, 128 exactly); 128 < K <= 256 the
+wide-model kernel (four lanes per pair, 48 / 64 states per lane, ghost-padded -- K = 130, 192 exactly, 200, 256
+exactly), whose sums over pairs still come from the runtime-K kernel.  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
 import numpy as np
 import pytest
 
@@ -25,9 +25,13 @@ def _problem(K, n_hap=64, S=200, seed=11):
 def _member(K):
     if K == 69:
         return 69
-    if K <= 80:
+    if K <= 128:
         return (K + 15) // 16 * 16
-    return -(32 if K <= 128 else 48 if K <= 192 else 64)
+    return -(48 if K <= 192 else 64)
+
+
+def _stride(K):
+    return 2 if _member(K) in (16, 32, 48, 64, 69, 96, 112, 128) else 1
 
 
 @pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 50, 64, 65, 70, 80, 81, 100, 128, 130, 192, 200, 256])
@@ -43,7 +47,7 @@ def test_generic_kernel_matches_oracle(K):
     want = O.decode_pairs_ibd(pm, folded, pairs, batch_size=64)
     got = ctx.decode_ibd(model, pr, groups)
     assert ctx.last_kernel() == _member(K)
-    assert ctx.last_beta_stride() == (2 if K <= 64 else 1)
+    assert ctx.last_beta_stride() == _stride(K)
     assert got.size == want.size
     for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"),
                           ("post_mean", "postMean"), ("map", "map")):
@@ -62,14 +66,14 @@ def test_generic_kernel_matches_oracle(K):
     np.testing.assert_array_equal(mean, wmean)
     np.testing.assert_array_equal(mp, wmap)
     s, _ = ctx.decode_sums(model)  # (K = 256 included: the transposition tile is sized for it)
-    assert ctx.last_kernel() == (_member(K) if K <= 80 else 0)
+    assert ctx.last_kernel() == (_member(K) if K <= 128 else 0)
     wsum = np.zeros((pm.S, pm.K), np.float32)
     O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
     np.testing.assert_array_equal(s, wsum)
     ctx.close()
 
 
-@pytest.mark.parametrize("K", [12, 40, 64])
+@pytest.mark.parametrize("K", [12, 40, 64, 100])
 def test_padded_members_stride_and_chunking(K):
     """The padded members through the checkpoint / rebuild layout and both beta strides: same records as the oracle."""
     pm, bits, folded = _problem(K, S=333, seed=5)
