@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
     // (obsIsZero / obsIsTwo of HMM.cpp:647-652 folded into a row select)
     auto obsClass = [&](const int q) -> int {
       const int wi = q >> 6;
-      if (wi != wordIdx) {
+      if (__builtin_expect(wi != wordIdx, 0)) { // once per 64 sites
         const unsigned long long wa = rowA[wi];
         const unsigned long long wb = rowB[wi];
         xw = wa ^ wb;
@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
     int rowVec = 0;
     auto stepRowOf = [&](const int site) -> int {
       const int blk = site >> 6;
-      if (blk != rowBlk) {
+      if (__builtin_expect(blk != rowBlk, 0)) { // once per 64 sites
         const int idx = blk * kWave + lane;
         rowVec = p.stepRow[idx < p.S ? idx : p.S - 1];
         rowBlk = blk;
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4, laneOff, b);
             return true;
           }
-        } else if (pos == ckPos && ckJ >= 1) {
+        } else if (__builtin_expect(pos == ckPos && ckJ >= 1, 0)) { // once per chunk
           store_vec<KT, KA>(K, ckpt + (size_t)ckJ * vecF4, laneOff, b);
           ckJ -= 1;
           ckPos = from + ckJ * C;
@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
         const int c = obsClass(pos);
         const float4* e = &emisLds[pos & 1][c * E4];
         FSMC_END(cycW, 4);
-        if (pos == from) {
+        if (__builtin_expect(pos == from, 0)) {
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
           alpha_step<KT, KA, true, SEQ>(K, a, w, tabs, stepRowOf(pos), e, cycW);
@@ -1914,7 +1914,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             }
             const int level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
             // a change of level (or a drop below every threshold) closes the open segment at pos-1
-            if (valid && cur != 4 && level != cur) {
+            if (__builtin_expect(valid && cur != 4 && level != cur, 0)) {
               emit(segStart, pos - 1);
             }
             const bool opening = level != 4 && level != cur;
@@ -1965,7 +1965,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
               segStart = pos;
             }
             cur = level;
-            if (pos == aEnd - 1) {
+            if (__builtin_expect(pos == aEnd - 1, 0)) {
               if (valid && cur != 4) {
                 emit(segStart, pos);
               }
