@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs on the GPU box: the side measurements of a round that are kept under profiles/ next to the headline profile
+# (tools/profile_bench.sh): C3 single-GPU point, C4 at size with rocprofv3 kernel stats + traffic, the short-window
+# (hashing) regime with kernel stats, the padded family members, the product path end to end.
+# Usage: tools/measure_round.sh <tag>
+set -u
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/round_$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+python3 bench.py --workload c3 --steps 2 --warmup 1 --cpu-pairs 0 > $OUT/c3_n1.json 2> $OUT/c3_n1.err
+echo "c3 done"
+bash tools/profile_bench.sh ${TAG}_c4 --states 256 --haps 256 --sites 200000 --steps 1 --warmup 1 > $OUT/c4_profile.log 2>&1
+echo "c4 done"
+python3 bench.py --states 256 --haps 600 --sites 3000 --steps 2 --warmup 1 --cpu-pairs 0 > $OUT/c4_reduced.json 2>/dev/null
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/short_trace -- python3 $GRAFT_REPO_ROOT/tools/measure_configs.py short > $OUT/short.json 2> $OUT/short.err )
+cp $(find $OUT/short_trace -name "*kernel_stats.csv" | head -1) $OUT/short_kernel_stats.csv 2>/dev/null
+echo "short done"
+: > $OUT/family.jsonl
+for K in 16 32 48 50 64 80 96 100 112 128 192; do
+  python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --states $K > $OUT/fam.json 2>/dev/null && cat $OUT/fam.json >> $OUT/family.jsonl
+done
+echo "family done"
+python3 tools/measure_configs.py run_c2 > $OUT/run_c2.json 2> $OUT/run_c2.err
+python3 tools/measure_configs.py c1 > $OUT/c1.json 2> $OUT/c1.err
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "all done"
