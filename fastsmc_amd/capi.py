@@ -273,6 +273,13 @@ class Model:
         keep = dict(pi=f32(pm.pi), cr=f32(pm.col_ratios), et=f32(pm.exp_times), D=f32(pm.D), B=f32(pm.B),
                     U=f32(pm.U), RR=f32(pm.RR), sr=np.ascontiguousarray(pm.step_row, dtype=np.int32),
                     e1=f32(pm.e1), e0m1=f32(pm.e0m1), e2m0=f32(pm.e2m0))
+        # the C side reads these with the shapes of fsmc_model_desc: a mis-shaped input must not be read out of bounds
+        rows = keep["D"].shape[0] if keep["D"].ndim == 2 else -1
+        for name, want in (("pi", (self.K,)), ("cr", (self.K,)), ("et", (self.K,)), ("D", (rows, self.K)),
+                           ("B", (rows, self.K)), ("U", (rows, self.K)), ("RR", (rows, self.K)), ("sr", (self.S,)),
+                           ("e1", (self.S, self.K)), ("e0m1", (self.S, self.K)), ("e2m0", (self.S, self.K))):
+            if keep[name].shape != want:
+                raise ValueError(f"model field {name}: shape {keep[name].shape}, expected {want}")
         d = _ModelDesc()
         d.K, d.S = self.K, self.S
         d.pi, d.col_ratios, d.exp_times = _p(keep["pi"]), _p(keep["cr"]), _p(keep["et"])
@@ -287,6 +294,10 @@ class Model:
             i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
             keep.update(gf=i32(pm.gap_row_f), sf=i32(pm.site_row_f), gb=i32(pm.gap_row_b), sb=i32(pm.site_row_b),
                         hom=f32(pm.hom))
+            for name, want in (("gf", (self.S,)), ("sf", (self.S,)), ("gb", (self.S,)), ("sb", (self.S,)),
+                               ("hom", (self.S, self.K))):
+                if keep[name].shape != want:
+                    raise ValueError(f"model field {name}: shape {keep[name].shape}, expected {want}")
             d.sequence = 1
             d.gap_row_f, d.site_row_f = _p(keep["gf"]), _p(keep["sf"])
             d.gap_row_b, d.site_row_b = _p(keep["gb"]), _p(keep["sb"])

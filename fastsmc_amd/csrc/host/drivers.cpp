@@ -2,8 +2,6 @@
 
 #include "hashing.hpp"
 
-#include "hashing.hpp"
-
 #include <stdexcept>
 
 namespace fsmc_host

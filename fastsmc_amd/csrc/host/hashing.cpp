@@ -21,6 +21,11 @@ HashingPrefilter::HashingPrefilter(const Data& data, const DecodingParams& param
   if (params.max_seeds != 0) {
     throw std::runtime_error("max_seeds != 0 (sub-hashing of large seeds) is not supported");
   }
+  if (!params.haploid) {
+    // the reference's default is haploid = true (DecodingParams.hpp:72); with false it keys matches by INDIVIDUAL pairs
+    // (ExtendHash::pairToLocation / locationToPair) and decodes haplotypes 2i, 2j only -- a different candidate set
+    throw std::runtime_error("haploid = false (matches keyed by individual) is not supported");
+  }
   mNumHaps = data.numHapRows();
   const size_t S = static_cast<size_t>(data.sites);
   if (params.min_maf <= 0.f) {

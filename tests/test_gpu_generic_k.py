@@ -106,3 +106,18 @@ def test_too_many_states_is_rejected():
     with pytest.raises(capi.FsmcError):
         ctx.create_model(big)
     ctx.close()
+
+
+def test_mis_shaped_model_arrays_are_rejected_before_the_c_call():
+    pm, bits, _ = _problem(16)
+    ctx = capi.Context(0)
+    import copy
+    bad = copy.copy(pm)
+    bad.e1 = pm.e1[:-1]  # one site short: fsmc_model_create would read S*K floats
+    with pytest.raises(ValueError, match="e1"):
+        ctx.create_model(bad)
+    bad = copy.copy(pm)
+    bad.D = pm.D[:, :-1]
+    with pytest.raises(ValueError, match="D"):
+        ctx.create_model(bad)
+    ctx.close()

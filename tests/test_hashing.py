@@ -187,3 +187,7 @@ def test_word_size_and_max_seeds_are_checked(hash_files):
     p.max_seeds = 5
     with pytest.raises(RuntimeError, match="max_seeds"):
         api.hashingCandidates(data, p)
+    p.max_seeds = 0
+    p.haploid = False  # matches keyed by individual pairs (ExtendHash.hpp): another candidate set, not built
+    with pytest.raises(RuntimeError, match="haploid"):
+        api.hashingCandidates(data, p)
