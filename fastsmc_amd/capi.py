@@ -27,7 +27,7 @@ FSMC_EOVERFLOW = -6
 SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
     "fsmc_ctx_set_chunk_sites", "fsmc_ctx_set_beta_stride", "fsmc_ctx_last_beta_stride", "fsmc_ctx_last_plan",
-    "fsmc_ctx_last_kernel",
+    "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items",
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
     "fsmc_decode_ibd",
@@ -86,6 +86,8 @@ def load():
         L.fsmc_ctx_last_beta_stride.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_ctx_last_plan.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.fsmc_ctx_last_kernel.argtypes = [vp, C.POINTER(i32)]
+        L.fsmc_ctx_set_pairing.argtypes = [vp, u32]
+        L.fsmc_ctx_last_items.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_model_create.argtypes = [vp, C.POINTER(_ModelDesc), C.POINTER(vp)]
         L.fsmc_model_destroy.argtypes = [vp]
         L.fsmc_model_destroy.restype = None
@@ -176,6 +178,15 @@ class Context:
         """Family member of the last launch: KT > 0 lane-per-pair, -KQ four lanes per pair, 0 runtime-K kernel."""
         v = C.c_int32(0)
         self._check(self._L.fsmc_ctx_last_kernel(self._h, C.byref(v)))
+        return v.value
+
+    def set_pairing(self, mode: int):
+        """1 (default): half-full groups with nearby windows share a wavefront; 0: groups run as uploaded."""
+        self._check(self._L.fsmc_ctx_set_pairing(self._h, mode))
+
+    def last_items(self) -> int:
+        v = C.c_int32(0)
+        self._check(self._L.fsmc_ctx_last_items(self._h, C.byref(v)))
         return v.value
 
     def set_workspace_limit(self, nbytes: int):

@@ -83,6 +83,26 @@ struct fsmc_ctx {
   int lastStride = 1;
   int lastMember = 0; // family member of the last launch: KT of the lane-per-pair kernel, -KQ of the q4 kernel
 
+  // The queues an IBD decode's waves pull from (fsmc_decode_ibd_launch): built from the uploaded groups once per
+  // work list and budget, longest window first.
+  struct IbdQueues {
+    uint64_t serial = 0;  // work list they were built from
+    uint64_t maxLen = 0;  // pairing budget they were built with
+    uint32_t pairing = 0;
+    bool valid = false;
+    bool dual = false;    // items/unions in use: two half-groups per wave
+    bool reordered = false; // rest is in use (a reordered copy or subset of the uploaded groups)
+    std::vector<fsmc_group> items, unions, rest;
+  } q;
+  uint64_t worklistSerial = 0;
+  fsmc_group* dItems = nullptr; // two half-groups per wave: {A, B} per item
+  fsmc_group* dRest = nullptr;  // the groups that run one per wave, longest window first
+  uint32_t pairing = 1;         // 0 = never pair half-full groups, 1 = automatic
+  int lastItems = 0;            // items of the last IBD launch (0: it ran on the groups as uploaded)
+  hipStream_t side = nullptr;   // the one-group-per-wave kernel of a paired decode runs here, beside the paired kernel
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  DevBuf wsSide;
+
   const fsmc_model* ibdModel = nullptr;
   uint32_t ibdFlags = 0;
   bool ibdPending = false;
@@ -213,8 +233,14 @@ int familyMember(const fsmc_model* m)
   return (m->K <= 128 && m->KP % kKPad == 0 && m->KP <= 128) ? m->KP : 0;
 }
 
-template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half)
+template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half, bool dual = false)
 {
+  if constexpr (KT > 0) {
+    if (dual && mode == kModeIbd && !seq) {
+      return track ? decode_kernel<KT, kModeIbd, true, false, false, true>
+                   : decode_kernel<KT, kModeIbd, false, false, false, true>;
+    }
+  }
   switch (mode) {
   case kModeIbd:
     if constexpr (halfBuilt(KT)) {
@@ -265,7 +291,7 @@ template <int KQ> KernelFn pickQuarterKernel(int mode, bool track)
   return decode_kernel_q4<KQ, kModeDump, false>;
 }
 
-KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
+KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false)
 {
   if (quarterLanes(mode, m)) {
     if (mode == kModeIbd) {
@@ -274,7 +300,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
     m->ctx->lastMember = -(m->KP / 4);
     return m->KP == 192 ? pickQuarterKernel<48>(mode, track) : pickQuarterKernel<64>(mode, track);
   }
-  const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1;
+  const bool half = !dual && halfAvailable(mode, m) && m->ctx->betaStride != 1;
   if (mode == kModeIbd) {
     m->ctx->lastStride = half ? 2 : 1;
   }
@@ -282,23 +308,23 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m)
   m->ctx->lastMember = member;
   switch (member) {
   case 16:
-    return pickMember<16>(mode, track, m->sequence, half);
+    return pickMember<16>(mode, track, m->sequence, half, dual);
   case 32:
-    return pickMember<32>(mode, track, m->sequence, half);
+    return pickMember<32>(mode, track, m->sequence, half, dual);
   case 48:
-    return pickMember<48>(mode, track, m->sequence, half);
+    return pickMember<48>(mode, track, m->sequence, half, dual);
   case 64:
-    return pickMember<64>(mode, track, m->sequence, half);
+    return pickMember<64>(mode, track, m->sequence, half, dual);
   case 69:
-    return pickMember<69>(mode, track, m->sequence, half);
+    return pickMember<69>(mode, track, m->sequence, half, dual);
   case 80:
-    return pickMember<80>(mode, track, m->sequence, half);
+    return pickMember<80>(mode, track, m->sequence, half, dual);
   case 96:
-    return pickMember<96>(mode, track, m->sequence, half);
+    return pickMember<96>(mode, track, m->sequence, half, dual);
   case 112:
-    return pickMember<112>(mode, track, m->sequence, half);
+    return pickMember<112>(mode, track, m->sequence, half, dual);
   case 128:
-    return pickMember<128>(mode, track, m->sequence, half);
+    return pickMember<128>(mode, track, m->sequence, half, dual);
   default:
     return pickMember<0>(mode, track, m->sequence, false);
   }
@@ -313,8 +339,14 @@ struct LaunchPlan {
 };
 
 // Decide chunking of the beta stream and the number of resident waves.
-int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan)
+// `items`: the list the waves will pull from when it is not the uploaded group list.  `paired`: two half-groups per
+// wave, `items` holding the union of each pair's windows; such launches store every beta row (stride 1).
+// `share`: the launch runs beside another one and may take 1/share of the workspace limit, in `ws`.
+int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan,
+               const std::vector<fsmc_group>* items = nullptr, bool paired = false, unsigned share = 1,
+               DevBuf* ws = nullptr)
 {
+  const std::vector<fsmc_group>& list = items ? *items : ctx->hGroups;
   int blocksPerCU = 0;
   FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fn, kWave, 0));
   if (blocksPerCU < 1) {
@@ -331,12 +363,12 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   }
   const bool q4 = quarterLanes(mode, m); // a wave takes a quarter of a group and holds 64 states per lane
   size_t slots = (size_t)ctx->nCU * blocksPerCU;
-  slots = std::min(slots, q4 ? 4 * ctx->nGroups : ctx->nGroups);
+  slots = std::min(slots, q4 ? 4 * list.size() : list.size());
   if (slots < 1) {
     slots = 1;
   }
   size_t L = 1;
-  for (const fsmc_group& g : ctx->hGroups) {
+  for (const fsmc_group& g : list) {
     const size_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
     L = std::max<size_t>(L, aEnd - g.from);
   }
@@ -344,9 +376,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   const int member = familyMember(m);
   const size_t K4 = q4 ? (size_t)m->KP / 16 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
   const size_t vecBytes = K4 * kWave * sizeof(float4);
-  const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes);
+  const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / share;
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
-  const bool half = halfAvailable(mode, m) && ctx->betaStride != 1;
+  const bool half = !paired && halfAvailable(mode, m) && ctx->betaStride != 1;
   auto chunkRows = [&](size_t c) { return half ? (c + 1) / 2 : c; };
   const size_t rowsAvail = (size_t)(limit / (vecBytes * slots)); // rows one resident wave may hold
   size_t C, maxChunks;
@@ -378,7 +410,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   plan.slots = (int)slots;
   ctx->lastChunk = plan.chunk;
   ctx->lastMaxChunks = plan.maxChunks;
-  return ensure(ctx, ctx->ws, plan.wsSlot * sizeof(float4) * slots);
+  return ensure(ctx, ws ? *ws : ctx->ws, plan.wsSlot * sizeof(float4) * slots);
 }
 
 int checkReady(fsmc_ctx* ctx, const fsmc_model* m)
@@ -471,6 +503,30 @@ int launch(fsmc_ctx* ctx, KernelFn fn, const KParams& p, int slots)
   return FSMC_OK;
 }
 
+// One decode as two kernels side by side: `pSide` (one group per wave; the long windows, so it starts first) on the
+// side stream and `pMain` (two half-groups per wave) on the context's stream.  They share the record buffer and its
+// counter and have a queue head each; the timed span covers both.
+int launchBeside(fsmc_ctx* ctx, KernelFn fnSide, KParams& pSide, int slotsSide, KernelFn fnMain, KParams& pMain,
+                 int slotsMain)
+{
+  FSMC_HIP(ctx, hipMemsetAsync(ctx->dCounters, 0, 4 * sizeof(unsigned), ctx->stream));
+  FSMC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  FSMC_HIP(ctx, hipEventRecord(ctx->evFork, ctx->stream));
+  FSMC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->evFork, 0));
+  pMain.groupBase = 0;
+  pSide.groupBase = 2;
+  hipLaunchKernelGGL(fnSide, dim3((unsigned)slotsSide), dim3(kWave), 0, ctx->side, pSide);
+  FSMC_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(fnMain, dim3((unsigned)slotsMain), dim3(kWave), 0, ctx->stream, pMain);
+  FSMC_HIP(ctx, hipGetLastError());
+  FSMC_HIP(ctx, hipEventRecord(ctx->evJoin, ctx->side));
+  FSMC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+  FSMC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->timed = true;
+  ctx->lastSlots = slotsSide + slotsMain;
+  return FSMC_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -537,6 +593,9 @@ int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
   }
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->dCounters, 4 * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->dPhase, 32 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(ctx->dPhase, 0, 32 * sizeof(unsigned long long));
@@ -561,6 +620,8 @@ void fsmc_ctx_destroy(fsmc_ctx* ctx)
   if (ctx->dHaps) (void)hipFree(ctx->dHaps);
   if (ctx->dPairs) (void)hipFree(ctx->dPairs);
   if (ctx->dGroups) (void)hipFree(ctx->dGroups);
+  if (ctx->dItems) (void)hipFree(ctx->dItems);
+  if (ctx->dRest) (void)hipFree(ctx->dRest);
   if (ctx->dCounters) (void)hipFree(ctx->dCounters);
   if (ctx->dPhase) (void)hipFree(ctx->dPhase);
   if (ctx->ws.p) (void)hipFree(ctx->ws.p);
@@ -569,6 +630,10 @@ void fsmc_ctx_destroy(fsmc_ctx* ctx)
   if (ctx->out.p) (void)hipFree(ctx->out.p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+  if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->wsSide.p) (void)hipFree(ctx->wsSide.p);
   if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -863,7 +928,112 @@ int fsmc_worklist_upload(fsmc_ctx* ctx, const fsmc_pair* pairs, size_t n_pairs, 
   ctx->nGroups = n_groups;
   ctx->hPairs.assign(pairs, pairs + n_pairs);
   ctx->hGroups.assign(groups, groups + n_groups);
+  ctx->worklistSerial += 1;
   ctx->ibdPending = false;
+  return FSMC_OK;
+}
+
+namespace
+{
+// Two half-groups per wavefront.  A group of at most 32 pairs (a hashing-mode batch) fills half a wave; two of them can
+// share one if the wave walks the union of their windows (decode_kernel<..., DUAL>).  Worth it when the union is not
+// much longer than the longer window: groups are sorted by (window length, from) and neighbours are paired while the
+// union stays within 1.25 x the longer one.  Returns false when the
+// list does not call for it (no half-full groups, or all of them were packed by the caller already).
+bool buildDualItems(const std::vector<fsmc_group>& groups, uint32_t maxLen, std::vector<fsmc_group>& items,
+                    std::vector<fsmc_group>& unions, std::vector<fsmc_group>& rest)
+{
+  // half-full groups whose window (and so the union with a neighbour of the same length class) fits the single-chunk
+  // layout are candidates; everything else -- full groups, long windows -- runs as uploaded, in a second kernel
+  std::vector<uint32_t> small;
+  for (size_t g = 0; g < groups.size(); ++g) {
+    if (groups[g].n_pairs <= 32 && (uint64_t)(groups[g].to - groups[g].from) * 5 <= (uint64_t)maxLen * 4) {
+      small.push_back((uint32_t)g);
+    }
+  }
+  if (small.size() < 2) {
+    return false;
+  }
+  // neighbours after this sort have windows of (nearly) the same length that start close to each other: the union a
+  // pair walks is then little longer than either window (lengths are compared in 64-site steps, the hashing word)
+  std::sort(small.begin(), small.end(), [&](uint32_t x, uint32_t y) {
+    const fsmc_group &a = groups[x], &b = groups[y];
+    const uint32_t la = (a.to - a.from + 63) / 64, lb = (b.to - b.from + 63) / 64;
+    return la != lb ? la < lb : a.from != b.from ? a.from < b.from : x < y;
+  });
+  items.clear();
+  unions.clear();
+  rest.clear();
+  std::vector<char> taken(groups.size(), 0);
+  for (size_t i = 0; i + 1 < small.size();) {
+    const fsmc_group &a = groups[small[i]], &b = groups[small[i + 1]];
+    const uint32_t lenA = a.to - a.from, lenB = b.to - b.from;
+    const uint32_t lenU = std::max(a.to, b.to) - std::min(a.from, b.from);
+    if ((uint64_t)lenU * 4 <= (uint64_t)std::max(lenA, lenB) * 5 && lenU <= maxLen) {
+      items.push_back(a);
+      items.push_back(b);
+      fsmc_group u = a;
+      u.from = std::min(a.from, b.from);
+      u.to = std::max(a.to, b.to);
+      u.scan_from = std::min(a.scan_from, b.scan_from);
+      u.scan_to = std::max(a.scan_to, b.scan_to);
+      unions.push_back(u);
+      taken[small[i]] = taken[small[i + 1]] = 1;
+      i += 2;
+    } else {
+      i += 1;
+    }
+  }
+  if (unions.empty()) {
+    return false;
+  }
+  // the pairs were made from the shortest class up: the waves pull them longest first
+  std::reverse(unions.begin(), unions.end());
+  for (size_t i = 0, j = items.size() - 2; i < j; i += 2, j -= 2) {
+    std::swap(items[i], items[j]);
+    std::swap(items[i + 1], items[j + 1]);
+  }
+  for (size_t g = 0; g < groups.size(); ++g) {
+    if (!taken[g]) {
+      rest.push_back(groups[g]);
+    }
+  }
+  return true;
+}
+
+// Longest window first: the decode ends when the last wave does, and a wave that pulls a long window late in the
+// queue runs on alone.  (The order of the queue is free: records are keyed by pair and sorted at fetch.)
+// Returns false when the list already is in that order (every window the same length, as in the all-pairs modes).
+bool longestFirst(std::vector<fsmc_group>& list)
+{
+  auto len = [](const fsmc_group& g) { return g.scan_to - g.from; };
+  bool ordered = true;
+  for (size_t i = 1; i < list.size() && ordered; ++i) {
+    ordered = len(list[i]) <= len(list[i - 1]);
+  }
+  if (ordered) {
+    return false;
+  }
+  std::stable_sort(list.begin(), list.end(), [&](const fsmc_group& a, const fsmc_group& b) { return len(a) > len(b); });
+  return true;
+}
+} // namespace
+
+int fsmc_ctx_set_pairing(fsmc_ctx* ctx, uint32_t mode)
+{
+  if (!ctx || mode > 1) {
+    return fail(ctx, FSMC_EINVAL, "pairing must be 0 (off) or 1 (automatic)");
+  }
+  ctx->pairing = mode;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items)
+{
+  if (!ctx || !n_items) {
+    return FSMC_EINVAL;
+  }
+  *n_items = ctx->lastItems;
   return FSMC_OK;
 }
 
@@ -875,12 +1045,69 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   const bool track = (flags & (FSMC_WANT_MEAN | FSMC_WANT_MAP)) != 0;
-  KernelFn fn = pickKernel(kModeIbd, track, m);
-  LaunchPlan plan;
-  rc = planLaunch(ctx, m, kModeIbd, fn, plan);
-  if (rc != FSMC_OK) {
-    return rc;
+  // The queues.  Two half-groups per wave for the half-full groups that pair up within the single-chunk layout at
+  // beta stride 1 (decode_kernel<..., DUAL>); the other groups one per wave, in a kernel that runs beside it.
+  KernelFn fnDual = nullptr;
+  uint64_t maxLen = 0;
+  if (ctx->pairing != 0 && !m->sequence && familyMember(m) > 0) {
+    fnDual = pickKernel(kModeIbd, track, m, true);
+    int blocksPerCU = 0;
+    FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fnDual, kWave, 0));
+    const size_t slots = (size_t)ctx->nCU * std::min(std::max(blocksPerCU, 1), 8);
+    const size_t vecBytes = (size_t)(familyMember(m) + 3) / 4 * kWave * sizeof(float4);
+    const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / 2;
+    const size_t rowsAvail = (size_t)(limit / (vecBytes * slots));
+    maxLen = rowsAvail > 16 ? std::min<size_t>(rowsAvail - 6, 1u << 30) : 0;
   }
+  fsmc_ctx::IbdQueues& q = ctx->q;
+  if (!q.valid || q.serial != ctx->worklistSerial || q.maxLen != maxLen || q.pairing != ctx->pairing) {
+    q.valid = false;
+    q.items.clear();
+    q.unions.clear();
+    q.rest.clear();
+    q.dual = maxLen > 0 && buildDualItems(ctx->hGroups, (uint32_t)maxLen, q.items, q.unions, q.rest);
+    if (!q.dual) {
+      q.rest = ctx->hGroups;
+    }
+    q.reordered = longestFirst(q.rest) || q.dual;
+    if (q.dual) {
+      rc = upload(ctx, &ctx->dItems, q.items.data(), q.items.size());
+      if (rc != FSMC_OK) {
+        return rc;
+      }
+    }
+    if (q.reordered && !q.rest.empty()) {
+      rc = upload(ctx, &ctx->dRest, q.rest.data(), q.rest.size());
+      if (rc != FSMC_OK) {
+        return rc;
+      }
+    }
+    q.serial = ctx->worklistSerial;
+    q.maxLen = maxLen;
+    q.pairing = ctx->pairing;
+    q.valid = true;
+  }
+  const bool haveRest = !q.rest.empty();
+  const bool beside = q.dual && haveRest;
+  LaunchPlan planDual, plan;
+  if (q.dual) {
+    rc = planLaunch(ctx, m, kModeIbd, fnDual, planDual, &q.unions, true, 2);
+    if (rc != FSMC_OK) {
+      return rc;
+    }
+    if (planDual.maxChunks != 1) {
+      return fail(ctx, FSMC_ESTATE, "paired launch does not fit the single-chunk layout");
+    }
+  }
+  KernelFn fn = pickKernel(kModeIbd, track, m, false); // (after the paired pick: last_kernel / last_beta_stride name this one)
+  if (haveRest) {
+    rc = planLaunch(ctx, m, kModeIbd, fn, plan, q.reordered ? &q.rest : nullptr, false, beside ? 2 : 1,
+                    beside ? &ctx->wsSide : nullptr);
+    if (rc != FSMC_OK) {
+      return rc;
+    }
+  }
+  ctx->lastItems = q.dual ? (int)q.unions.size() : 0;
   if (ctx->recCap == 0) {
     ctx->recCap = std::max<size_t>(1u << 16, 8 * ctx->nPairs);
   }
@@ -888,9 +1115,24 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   if (rc != FSMC_OK) {
     return rc;
   }
-  KParams p;
-  fillParams(ctx, m, plan, flags, p);
-  rc = launch(ctx, fn, p, plan.slots);
+  KParams pDual, p;
+  if (q.dual) {
+    fillParams(ctx, m, planDual, flags, pDual);
+    pDual.groups = ctx->dItems;
+    pDual.nGroups = (int)q.unions.size();
+  }
+  if (haveRest) {
+    fillParams(ctx, m, plan, flags, p);
+    if (q.reordered) {
+      p.groups = ctx->dRest;
+      p.nGroups = (int)q.rest.size();
+    }
+    if (beside) {
+      p.ws = (float4*)ctx->wsSide.p;
+    }
+  }
+  rc = beside ? launchBeside(ctx, fn, p, plan.slots, fnDual, pDual, planDual.slots)
+              : q.dual ? launch(ctx, fnDual, pDual, planDual.slots) : launch(ctx, fn, p, plan.slots);
   if (rc != FSMC_OK) {
     return rc;
   }

@@ -7,6 +7,9 @@ namespace fsmc
 {
 #if defined(FSMC_INSTANCE_KT)
 FSMC_KT_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
+#if FSMC_INSTANCE_KT > 0
+FSMC_DEFINE_KT_DUAL(FSMC_INSTANCE_KT)
+#endif
 #if FSMC_INSTANCE_KT == 16 || FSMC_INSTANCE_KT == 32 || FSMC_INSTANCE_KT == 48 || FSMC_INSTANCE_KT == 64 ||           \
     FSMC_INSTANCE_KT == 69 || FSMC_INSTANCE_KT == 96 || FSMC_INSTANCE_KT == 112 || FSMC_INSTANCE_KT == 128
 static_assert(halfBuilt(FSMC_INSTANCE_KT), "keep halfBuilt() and this list in step");

@@ -49,6 +49,13 @@ constexpr bool halfBuilt(const int KT)
   extern template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
 #define FSMC_DEFINE_KT(KT, MODE, TRACK, SEQ, HALF)                                                                     \
   template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
+// two half-groups per wavefront (hashing-mode work lists): array-mode IBD decode, beta stride 1
+#define FSMC_DECLARE_KT_DUAL(KT)                                                                                       \
+  extern template __global__ void decode_kernel<KT, kModeIbd, true, false, false, true>(const KParams);              \
+  extern template __global__ void decode_kernel<KT, kModeIbd, false, false, false, true>(const KParams);
+#define FSMC_DEFINE_KT_DUAL(KT)                                                                                        \
+  template __global__ void decode_kernel<KT, kModeIbd, true, false, false, true>(const KParams);                     \
+  template __global__ void decode_kernel<KT, kModeIbd, false, false, false, true>(const KParams);
 #define FSMC_DECLARE_Q4(KQ, MODE, TRACK) extern template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 #define FSMC_DEFINE_Q4(KQ, MODE, TRACK) template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 
@@ -67,6 +74,15 @@ FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 69)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 96)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 112)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 128)
+FSMC_DECLARE_KT_DUAL(16)
+FSMC_DECLARE_KT_DUAL(32)
+FSMC_DECLARE_KT_DUAL(48)
+FSMC_DECLARE_KT_DUAL(64)
+FSMC_DECLARE_KT_DUAL(69)
+FSMC_DECLARE_KT_DUAL(80)
+FSMC_DECLARE_KT_DUAL(96)
+FSMC_DECLARE_KT_DUAL(112)
+FSMC_DECLARE_KT_DUAL(128)
 #define FSMC_DECLARE_Q4_MEMBER(KQ) FSMC_Q4_KERNELS(FSMC_DECLARE_Q4, KQ)
 FSMC_ALL_Q4(FSMC_DECLARE_Q4_MEMBER)
 #endif

@@ -47,7 +47,8 @@ struct KParams {
   int S;       // sites
   int W;       // 64-bit words per haplotype row
   int nGroups;
-  int groupBase; // kModeSums: this launch decodes groups groupBase .. groupBase + gridDim.x - 1, one per wave
+  int groupBase; // kModeSums: this launch decodes groups groupBase .. groupBase + gridDim.x - 1, one per wave;
+                 // other modes: which of `counters` is this launch's queue head
   int chunk;   // sites per chunk (C)
   int chunkRows; // rows of the chunk buffer: C, or (C+1)/2 with beta stride 2
   int maxChunks;
@@ -69,7 +70,7 @@ struct KParams {
   const unsigned long long* haps; // [nHaps][W]
   const fsmc_pair* pairs;
   const fsmc_group* groups;
-  unsigned* counters; // [0] group queue head, [1] IBD record count
+  unsigned* counters; // [groupBase] head of the group queue the launch pulls from (0, or 2 beside another launch), [1] IBD record count
   float4* ws;         // workspace, wsSlot float4 per resident wave
   size_t wsSlot;
   unsigned stateThr, ageThr;
@@ -1178,10 +1179,18 @@ constexpr int minWavesPerSimd(const int KT)
 {
   return KT > 80 ? 1 : 2;
 }
-template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF>
+//
+// DUAL: two half-groups per wavefront (hashing mode: a batch is 32 pairs, half a wave).  Lanes 0..31 decode half A, lanes
+// 32..63 half B, each over ITS OWN decode and scan window; the wave walks the union of the two windows and a lane is
+// (re)initialised where its own window opens -- beta at site to-1 of its window, alpha at site from -- so within its
+// window every value is produced by exactly the operations of a stand-alone decode (what a lane computes outside its
+// window is overwritten before it is used and never reaches an output).  Single-chunk layout, beta stride 1; the
+// work list is an array of item = {group A, group B} (B may be empty) prepared by the host library.
+template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF, bool DUAL = false>
 __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(const KParams p)
 {
   static_assert(!HALF || (!SEQ && MODE == kModeIbd), "beta stride 2 is built for the array-mode IBD decode");
+  static_assert(!DUAL || (MODE == kModeIbd && !SEQ && !HALF && KT > 0), "two half-groups per wave: array-mode IBD, stride 1");
   // array mode with a compile-time K: the backward loops are rotated (operand-free step tails overlap the next
   // step's first operand requests)
   constexpr bool kRotate = KT > 0 && kPacked && !SEQ;
@@ -1241,22 +1250,46 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
       g = round == 0 ? (unsigned)p.groupBase + blockIdx.x : (unsigned)p.nGroups;
     } else {
       if (lane == 0) {
-        g = atomicAdd(&p.counters[0], 1u);
+        g = atomicAdd(&p.counters[p.groupBase], 1u);
       }
       g = __builtin_amdgcn_readfirstlane(g);
     }
     if (g >= (unsigned)p.nGroups) {
       break;
     }
-    const cuint_p gw = (cuint_p)(p.groups + g);
+    const cuint_p gw = (cuint_p)(p.groups + (DUAL ? 2 * (size_t)g : (size_t)g));
     const unsigned firstPair = gw[0];
     const int nPairsInGroup = (int)gw[1];
-    const int from = (int)gw[2];
-    const int to = (int)gw[3];
-    const int scanFrom = (int)gw[4];
-    const int aEnd = (MODE == kModeIbd) ? (int)gw[5] : to; // the alpha sweep stops here
-    const bool valid = lane < nPairsInGroup;
-    const unsigned pairIdx = firstPair + (valid ? (unsigned)lane : 0u);
+    int from = (int)gw[2];
+    int to = (int)gw[3];
+    int scanFrom = (int)gw[4];
+    int aEnd = (MODE == kModeIbd) ? (int)gw[5] : to; // the alpha sweep stops here
+    bool valid = lane < nPairsInGroup;
+    unsigned pairIdx = firstPair + (valid ? (unsigned)lane : 0u);
+    // DUAL: this lane's own windows, and the wave-uniform windows of the two halves
+    int myFrom = from, myTo = to, mySF = scanFrom, myST = aEnd;
+    int toA = to, toB = to, fromA = from, fromB = from, stA = aEnd, stB = aEnd;
+    if constexpr (DUAL) {
+      const int nB = (int)gw[7];
+      if (nB > 0) {
+        fromB = (int)gw[8];
+        toB = (int)gw[9];
+        stB = (int)gw[11];
+        const bool half = lane >= 32;
+        valid = half ? (lane - 32 < nB) : (lane < nPairsInGroup);
+        pairIdx = half ? gw[6] + (valid ? (unsigned)(lane - 32) : 0u) : firstPair + (valid ? (unsigned)lane : 0u);
+        myFrom = half ? fromB : fromA;
+        myTo = half ? toB : toA;
+        mySF = half ? (int)gw[10] : scanFrom;
+        myST = half ? stB : stA;
+        from = fromA < fromB ? fromA : fromB;
+        to = toA > toB ? toA : toB;
+        scanFrom = scanFrom < (int)gw[10] ? scanFrom : (int)gw[10];
+        aEnd = stA > stB ? stA : stB;
+      } else {
+        valid = lane < nPairsInGroup && lane < 32;
+      }
+    }
     const fsmc_pair pr = p.pairs[pairIdx];
     const unsigned long long* rowA = p.haps + (size_t)pr.hap_a * p.W;
     const unsigned long long* rowB = p.haps + (size_t)pr.hap_b * p.W;
@@ -1448,9 +1481,24 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             w[k] = (!kGhost<KT> || k < p.K) ? 1.0f : 0.f;
             bsum = bsum + w[k];
           }
+          const float bsumInit = bsum;
+          // DUAL: the lanes whose own window ends at site q start from beta = 1 there (HMM.cpp:887-897)
+          auto openBeta = [&](const int q) {
+            if constexpr (DUAL) {
+              if (q == toA - 1 || q == toB - 1) {
+                const bool sel = myTo - 1 == q;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  w[k] = sel ? ((!kGhost<KT> || k < p.K) ? 1.0f : 0.f) : w[k];
+                }
+                bsum = sel ? bsumInit : bsum;
+              }
+            }
+          };
           bool stored = false;
           for (int pos = to - 2; pos >= from; --pos) {
             const int q = pos + 1;
+            openBeta(q);
             waitEmisRows(stored); // the rows of site q have landed
             __builtin_amdgcn_wave_barrier();
             if (pos - 1 >= from) {
@@ -1468,6 +1516,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             FSMC_END(cycW, 1);
             bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, e, tabs.ghostMask, cycW);
           }
+          openBeta(from);
           scale_pk<KT, KA>(b, w, bsum);
           afterBeta(from);
         } else {
@@ -1675,6 +1724,17 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
           alpha_step<KT, KA, true, SEQ>(K, a, w, tabs, stepRowOf(pos), e, cycW);
+          if constexpr (DUAL) {
+            // the lanes whose own window opens here start from pi * emission (HMM.cpp:736-747)
+            if (pos == fromA || pos == fromB) {
+              alpha_init<KT, KA>(K, w, tPi, e);
+              const bool sel = myFrom == pos;
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                a[k] = sel ? w[k] : a[k];
+              }
+            }
+          }
         }
         if constexpr (SEQ) {
           // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step
@@ -1912,7 +1972,12 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
                 }
               }
             }
-            const int level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
+            int level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
+            if constexpr (DUAL) {
+              if (!(pos >= mySF && pos < myST)) {
+                level = 4; // outside this lane's own scan window
+              }
+            }
             // a change of level (or a drop below every threshold) closes the open segment at pos-1
             if (__builtin_expect(valid && cur != 4 && level != cur, 0)) {
               emit(segStart, pos - 1);
@@ -1965,7 +2030,16 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
               segStart = pos;
             }
             cur = level;
-            if (__builtin_expect(pos == aEnd - 1, 0)) {
+            if constexpr (DUAL) {
+              if (__builtin_expect(pos == stA - 1 || pos == stB - 1, 0)) {
+                if (pos == myST - 1) { // the last site of this lane's scan window closes its open segment
+                  if (valid && cur != 4) {
+                    emit(segStart, pos);
+                  }
+                  cur = 4;
+                }
+              }
+            } else if (__builtin_expect(pos == aEnd - 1, 0)) {
               if (valid && cur != 4) {
                 emit(segStart, pos);
               }

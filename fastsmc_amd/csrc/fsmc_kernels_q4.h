@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kWave, FSMC_Q4_MINBLOCKS(KQ)) void decode_kernel_q4
   for (;;) {
     unsigned item = 0;
     if (lane == 0) {
-      item = atomicAdd(&p.counters[0], 1u);
+      item = atomicAdd(&p.counters[p.groupBase], 1u);
     }
     item = __builtin_amdgcn_readfirstlane(item);
     const unsigned g = item >> 2;

@@ -134,6 +134,12 @@ int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
 /* How the last launch was laid out: sites per chunk (= the longest window when every beta row fitted), chunks per
  * window, resident waves. */
 int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_chunks, int32_t* n_slots);
+/* Two half-groups per wavefront.  A group of at most 32 pairs (a hashing-mode batch of the reference's default size)
+ * fills half a wave; with pairing = 1 (default) the IBD decode puts two such groups with nearby windows on one wave,
+ * each lane still decoded over its own group's windows (results do not depend on it).  0 = never.
+ * fsmc_ctx_last_items: wave work items of the last IBD launch when it paired groups, 0 when it ran them as uploaded. */
+int fsmc_ctx_set_pairing(fsmc_ctx* ctx, uint32_t mode);
+int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items);
 /* Which kernel family member the last launch ran: n > 0 = the lane-per-pair kernel compiled for n states (69, or
  * the padded members 16, 32, 48, 64, 80), n < 0 = the four-lanes-per-pair kernel with -n states per lane
  * (80 < K <= 256), 0 = the runtime-K kernel (wide models in the modes the four-lane kernel does not have). */

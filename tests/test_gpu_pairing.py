@@ -1,0 +1,123 @@
+"""Two half-groups per wavefront (decode_kernel<..., DUAL>; fsmc_ctx_set_pairing): hashing-mode batches of at most 32
+pairs share a wave, each lane decoded over its OWN group's decode and scan windows.  The records must be the bytes of
+the unpaired run (and of the oracle): different windows in the two halves, a half that starts later / ends earlier than
+the other, one-site windows, ragged halves, segment ages on and off, several family members.  Groups that do not pair
+(more than 32 pairs, or a window too long for the paired kernel's single-chunk layout) run in a second kernel of the
+same decode and land in the same record list."""
+import numpy as np
+import pytest
+
+from fastsmc_amd import capi, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FIELDS = (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"), ("post_mean", "postMean"),
+          ("map", "map"))
+
+
+def _oracle(pm, folded, pairs, wins, want_mean, want_map):
+    S, out = pm.S, []
+    for first, cnt, frm, to, sfrm, sto in wins:
+        sub = pairs[first:first + cnt]
+        ob = np.stack([(folded[a] ^ folded[b])[frm:to] for a, b in sub])
+        hb = np.stack([(folded[a] & folded[b])[frm:to] for a, b in sub])
+        post, _ = O.decode_batch(pm, ob, hb, frm, to)
+        full = np.zeros((S, pm.K, cnt), np.float32)
+        full[frm:to] = post[frm:to]
+        for v in range(cnt):
+            out.append(O.ibd_scan_pair(pm, full, v, sfrm, sto, want_mean=want_mean, want_map=want_map,
+                                       pair_ordinal=first + v))
+    return np.concatenate(out)
+
+
+def _run(ctx, model, pairs, wins, flags, pairing):
+    groups = np.zeros(len(wins), capi.GROUP_DTYPE)
+    for g, w in zip(groups, wins):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    ctx.set_pairing(pairing)
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    rec = ctx.decode_ibd(model, pr, groups, flags)
+    return rec, ctx.last_items()
+
+
+@pytest.mark.parametrize("flags", [capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP, 0])
+def test_paired_half_groups_match_the_unpaired_run_and_the_oracle(small_problem, flags):
+    pm, folded, S = small_problem["model"], small_problem["folded"], small_problem["model"].S
+    allp = O.enumerate_all_pairs(32)
+    # (count, from, to, scan_from, scan_to): windows chosen so that the sort pairs different ones
+    shapes = [(32, 100, 420, 110, 400), (32, 120, 440, 130, 430),      # overlapping, B starts and ends later
+              (17, 0, 300, 0, 300), (32, 5, 320, 40, 310),             # ragged half, window at the sequence start
+              (32, 300, S, 320, S), (9, 330, S, 330, S - 1),           # windows ending at the last site
+              (1, 200, 201, 200, 201), (32, 200, 202, 200, 202),       # one- and two-site windows
+              (64, 50, 500, 60, 480), (40, 60, 510, 60, 510),          # full groups: second kernel of the same decode
+              (32, 10, 600, 300, 310), (32, 20, 610, 25, 600)]         # a short scan window inside a long decode window
+    wins, first = [], 0
+    for cnt, frm, to, sf, st in shapes:
+        wins.append((first, cnt, frm, to, sf, st))
+        first += cnt
+    pairs = allp[7:7 + first]
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(small_problem["bits"], S)
+    plain, n0 = _run(ctx, model, pairs, wins, flags, pairing=0)
+    paired, n1 = _run(ctx, model, pairs, wins, flags, pairing=1)
+    ctx.close()
+    assert n0 == 0 and 0 < n1 < len(wins)  # the second run really put two groups on one wave
+    assert paired.tobytes() == plain.tobytes()
+    want = _oracle(pm, folded, pairs, wins, bool(flags & capi.FSMC_WANT_MEAN), bool(flags & capi.FSMC_WANT_MAP))
+    assert paired.size == want.size and want.size > 10
+    for f_got, f_want in FIELDS:
+        np.testing.assert_array_equal(paired[f_got], want[f_want], err_msg=f_got)
+
+
+@pytest.mark.parametrize("K", [12, 100])
+def test_pairing_in_the_padded_members(K):
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(64, 500, seed=9, cm_per_mb=25.0, switch_per_cm=0.6)
+    bits, derived, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    pm = O.prepare_model(tables, (haps.cm / 100.0).astype(np.float32), haps.bp, derived, 64, time=200)
+    allp = O.enumerate_all_pairs(32)
+    wins = [(0, 32, 50, 350, 60, 340), (32, 30, 70, 380, 70, 380), (62, 32, 200, 500, 210, 500), (94, 5, 190, 480, 190, 470)]
+    pairs = allp[:99]
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    plain, _ = _run(ctx, model, pairs, wins, capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP, 0)
+    paired, n1 = _run(ctx, model, pairs, wins, capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP, 1)
+    ctx.close()
+    assert n1 == 2 and paired.tobytes() == plain.tobytes()
+    want = _oracle(pm, folded, pairs, wins, True, True)
+    assert paired.size == want.size
+    for f_got, f_want in FIELDS:
+        np.testing.assert_array_equal(paired[f_got], want[f_want], err_msg=f_got)
+
+
+def test_windows_too_long_to_pair_run_in_the_second_kernel(small_problem):
+    """With a small workspace the long windows exceed the paired kernel's single-chunk budget: they go to the second
+    kernel while the short ones still pair."""
+    pm, folded, S = small_problem["model"], small_problem["folded"], small_problem["model"].S
+    allp = O.enumerate_all_pairs(32)
+    shapes = [(32, 0, S, 0, S), (32, 100, 180, 100, 180), (32, 110, 190, 110, 190), (20, 5, S - 3, 10, S - 3),
+              (32, 400, 470, 400, 470), (32, 402, 480, 402, 480), (32, 0, S, 50, 600)]
+    wins, first = [], 0
+    for cnt, frm, to, sf, st in shapes:
+        wins.append((first, cnt, frm, to, sf, st))
+        first += cnt
+    pairs = allp[3:3 + first]
+    flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(small_problem["bits"], S)
+    # the pairing budget is what a FULL machine of resident waves could hold in half of the workspace: ~200 rows of
+    # 18 float4 x 64 lanes per wave on 256 CUs x 8 waves -- enough for the 80-site windows, not for the 640-site ones
+    ctx.set_workspace_limit(2 * 200 * 18 * 64 * 16 * 256 * 8)
+    plain, n0 = _run(ctx, model, pairs, wins, flags, pairing=0)
+    paired, n1 = _run(ctx, model, pairs, wins, flags, pairing=1)
+    ctx.close()
+    assert n0 == 0 and n1 == 2
+    assert paired.tobytes() == plain.tobytes()
+    want = _oracle(pm, folded, pairs, wins, True, True)
+    assert paired.size == want.size
+    for f_got, f_want in FIELDS:
+        np.testing.assert_array_equal(paired[f_got], want[f_want], err_msg=f_got)

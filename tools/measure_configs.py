@@ -220,12 +220,16 @@ def short_windows():
     model = ctx.create_model(pm)
     ctx.upload_haps(bits, pm.S)
     ctx.upload_worklist(pr, groups)
-    dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1])
     ps = float((lens.astype(np.int64) * 32).sum())
-    print(json.dumps({"config": "short_windows_ibd", "groups": n_groups, "pairs": int(pr.size), "pair_sites": ps,
-                      "seconds": dt, "kernel_ms": ctx.last_kernel_ms(), "pair_sites_per_s": ps / dt,
-                      "pairs_per_s": pr.size / dt, "algorithmic_GBps": ps * (8 * 69 + 0.25) / dt / 1e9,
-                      "records": int(rec.size), "plan": ctx.info()}))
+    for pairing in (1, 0):
+        ctx.set_pairing(pairing)
+        dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1])
+        print(json.dumps({"config": "short_windows_ibd", "pairing": pairing, "wave_items": ctx.last_items(),
+                          "beta_stride": ctx.last_beta_stride(), "groups": n_groups, "pairs": int(pr.size),
+                          "pair_sites": ps, "seconds": dt, "kernel_ms": ctx.last_kernel_ms(),
+                          "pair_sites_per_s": ps / dt, "pairs_per_s": pr.size / dt,
+                          "algorithmic_GBps": ps * (8 * 69 + 0.25) / dt / 1e9, "records": int(rec.size),
+                          "plan": ctx.info()}))
     ctx.close()
 
 
