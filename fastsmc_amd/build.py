@@ -50,8 +50,8 @@ def hip_source_hash() -> str:
 
 
 def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
-    """hipcc cross-compiles the gfx950 code objects without a GPU: fsmc_capi.hip (host side + kernel selection) and
-    fsmc_inst.hip once per family member, in parallel, linked into one shared library."""
+    """hipcc cross-compiles the gfx950 code objects without a GPU: fsmc_capi.hip (host side + kernel selection),
+    fsmc_identify_sort.hip (rocPRIM sort of the identification step's candidates) and fsmc_inst.hip once per family member, in parallel, linked into one shared library."""
     srcs = hip_sources()
     if not force and _newer(HIP_LIB, srcs):
         return HIP_LIB
@@ -59,7 +59,8 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c"]
     if verbose:
         cflags.append("-Rpass-analysis=kernel-resource-usage")
-    units = [("capi", os.path.join(CSRC, "fsmc_capi.hip"), [])]
+    units = [("capi", os.path.join(CSRC, "fsmc_capi.hip"), []),
+             ("idsort", os.path.join(CSRC, "fsmc_identify_sort.hip"), [])]
     units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"]) for k in KT_MEMBERS]
     units += [(f"q4_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_Q4={k}"]) for k in Q4_MEMBERS]
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))

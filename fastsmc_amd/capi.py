@@ -32,11 +32,13 @@ SYMBOLS = [
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
     "fsmc_decode_ibd",
     "fsmc_decode_posteriors", "fsmc_decode_per_pair", "fsmc_decode_sums",
+    "fsmc_identify",
 ]
 
 PAIR_DTYPE = np.dtype([("hap_a", "<u4"), ("hap_b", "<u4")])
 GROUP_DTYPE = np.dtype([("first_pair", "<u4"), ("n_pairs", "<u4"), ("from", "<u4"), ("to", "<u4"),
                         ("scan_from", "<u4"), ("scan_to", "<u4")])
+CANDIDATE_DTYPE = np.dtype([("hap_a", "<u4"), ("hap_b", "<u4"), ("from", "<u4"), ("to", "<u4"), ("flush_word", "<u4")])
 IBD_DTYPE = np.dtype([("pair", "<u4"), ("start", "<i4"), ("end", "<i4"), ("prob", "<f4"), ("post_mean", "<f4"),
                       ("map", "<f4")])
 
@@ -45,6 +47,11 @@ class FsmcError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"fastsmc_hip error {code}: {msg}")
         self.code = code
+
+
+class _JobWindow(C.Structure):
+    _fields_ = [("window_size", C.c_uint32), ("w_i", C.c_uint32), ("w_j", C.c_uint32), ("last_job", C.c_int32),
+                ("j_above_diag", C.c_int32)]
 
 
 class _ModelDesc(C.Structure):
@@ -102,6 +109,8 @@ def load():
         L.fsmc_decode_posteriors.argtypes = [vp, vp, vp, sz]
         L.fsmc_decode_per_pair.argtypes = [vp, vp, vp, vp, vp]
         L.fsmc_decode_sums.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.fsmc_identify.argtypes = [vp, vp, u32, u32, vp, C.POINTER(_JobWindow), vp, u32, i32, C.c_float, C.c_float, vp,
+                                    sz, C.POINTER(sz)]
         _lib = L
     return _lib
 
@@ -241,6 +250,31 @@ class Context:
         self.upload_worklist(pairs, groups)
         self.decode_ibd_launch(model, flags)
         return self.decode_ibd_fetch()
+
+    def identify(self, words, global_ids, gen_pos, *, window_size=0, w_i=1, w_j=1, last_job=True, j_above_diag=False,
+                 gap=1, skip=0.0, min_m=1.0) -> np.ndarray:
+        """The identification step (fsmc_identify): candidates (hap_a, hap_b, from, to, flush_word) in emission order.
+        ``words``: uint64 [n_haps][n_words]; ``global_ids``: haplotype numbers in the whole file; ``gen_pos``: Morgans
+        per site.  The defaults of the job window are those of a single job (every pair belongs to it)."""
+        w = np.ascontiguousarray(words, np.uint64)
+        if w.ndim != 2:
+            raise ValueError("words must be [n_haps][n_words]")
+        ids = np.ascontiguousarray(global_ids, np.uint32)
+        gen = np.ascontiguousarray(gen_pos, np.float32)
+        if ids.shape != (w.shape[0],):
+            raise ValueError("global_ids must have one entry per haplotype")
+        jw = _JobWindow(window_size, w_i, w_j, int(bool(last_job)), int(bool(j_above_diag)))
+        cap = max(1024, 4 * w.shape[0])
+        while True:
+            out = np.zeros(cap, CANDIDATE_DTYPE)
+            n = C.c_size_t(0)
+            rc = self._L.fsmc_identify(self._h, _p(w), w.shape[0], w.shape[1], _p(ids), C.byref(jw), _p(gen), gen.size,
+                                       gap, skip, min_m, _p(out), cap, C.byref(n))
+            if rc == -6:  # FSMC_EOVERFLOW: n holds the count
+                cap = int(n.value)
+                continue
+            self._check(rc)
+            return out[:n.value]
 
     def decode_per_pair(self, model: "Model", exp_coal_times, want_mean=True, want_map=True):
         """writePerPairOutput for the resident work list: (mean[n_pairs][S] f32, map[n_pairs][S] i32)."""

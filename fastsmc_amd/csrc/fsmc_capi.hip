@@ -16,7 +16,14 @@
 #include <string>
 #include <vector>
 
+#include "fsmc_identify.h"
 #include "fsmc_instances.h"
+
+namespace fsmc
+{
+hipError_t idSortCandidates(hipStream_t stream, const fsmc_candidate* in, fsmc_candidate* sorted, unsigned n,
+                            unsigned nHaps, unsigned nWords); // fsmc_identify_sort.hip
+}
 
 using namespace fsmc;
 
@@ -1139,6 +1146,116 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   ctx->ibdModel = m;
   ctx->ibdFlags = flags;
   ctx->ibdPending = true;
+  return FSMC_OK;
+}
+
+int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_t n_words, const uint32_t* global_ids,
+                  const fsmc_job_window* job, const float* gen_pos, uint32_t n_sites, int32_t gap, float skip,
+                  float min_m, fsmc_candidate* out, size_t cap, size_t* n_out)
+{
+  if (!ctx) {
+    return FSMC_EINVAL;
+  }
+  if (!n_out) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: n_out is null");
+  }
+  *n_out = 0;
+  if (n_haps < 2 || n_words == 0) {
+    return FSMC_OK; // no pair, or no complete word (FastSMC.cpp:186-195 hashes complete words only)
+  }
+  if (!words || !global_ids || !job || !gen_pos || (cap && !out)) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: null argument");
+  }
+  if ((uint64_t)n_words * 64u > n_sites) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: n_words * 64 exceeds n_sites");
+  }
+  if (gap < 0 || cap > 0xFFFFFFFFull) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: gap < 0 or cap beyond 2^32");
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  const unsigned tiles = (n_haps + kIdTile - 1) / kIdTile;
+  const unsigned chunks = (n_words + kIdChunk - 1) / kIdChunk;
+  // device buffers of this call (one call per job: no caching)
+  struct Bufs {
+    void* p[7] = {};
+    ~Bufs()
+    {
+      for (void* q : p) {
+        if (q) {
+          (void)hipFree(q);
+        }
+      }
+    }
+  } b;
+  const size_t bytes[7] = {(size_t)n_haps * n_words * sizeof(uint64_t),
+                           (size_t)n_haps * sizeof(uint32_t),
+                           (size_t)n_sites * sizeof(float),
+                           (size_t)chunks * tiles * kIdTile * sizeof(unsigned),
+                           (size_t)chunks * sizeof(unsigned),
+                           std::max<size_t>(cap, 1) * sizeof(fsmc_candidate),
+                           sizeof(unsigned)};
+  for (int i = 0; i < 7; ++i) {
+    const hipError_t e = hipMalloc(&b.p[i], bytes[i]);
+    if (e != hipSuccess) {
+      b.p[i] = nullptr;
+      return fail(ctx, FSMC_ENOMEM, std::string("fsmc_identify: hipMalloc failed: ") + hipGetErrorString(e));
+    }
+  }
+  FSMC_HIP(ctx, hipMemcpyAsync(b.p[0], words, bytes[0], hipMemcpyHostToDevice, ctx->stream));
+  FSMC_HIP(ctx, hipMemcpyAsync(b.p[1], global_ids, bytes[1], hipMemcpyHostToDevice, ctx->stream));
+  FSMC_HIP(ctx, hipMemcpyAsync(b.p[2], gen_pos, bytes[2], hipMemcpyHostToDevice, ctx->stream));
+  FSMC_HIP(ctx, hipMemsetAsync(b.p[3], 0, bytes[3], ctx->stream));
+  FSMC_HIP(ctx, hipMemsetAsync(b.p[6], 0, bytes[6], ctx->stream));
+  IdParams p;
+  p.words = (const unsigned long long*)b.p[0];
+  p.nHaps = n_haps;
+  p.nWords = n_words;
+  p.globalId = (const unsigned*)b.p[1];
+  p.job = *job;
+  p.gen = (const float*)b.p[2];
+  p.nSites = n_sites;
+  p.gap = gap;
+  p.skip = skip;
+  p.minM = min_m;
+  p.dupBits = (unsigned*)b.p[3];
+  p.hapStride = tiles * kIdTile;
+  p.usedBits = (unsigned*)b.p[4];
+  p.out = (fsmc_candidate*)b.p[5];
+  p.cap = (unsigned)cap;
+  p.count = (unsigned*)b.p[6];
+  FSMC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(id_dup_kernel, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
+  FSMC_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(id_complexity_kernel, dim3(chunks), dim3(kIdThreads), 0, ctx->stream, p);
+  FSMC_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(id_match_kernel, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
+  FSMC_HIP(ctx, hipGetLastError());
+  FSMC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->timed = true;
+  unsigned count = 0;
+  FSMC_HIP(ctx, hipMemcpyAsync(&count, b.p[6], sizeof(count), hipMemcpyDeviceToHost, ctx->stream));
+  FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_out = count;
+  if (count > cap) {
+    return fail(ctx, FSMC_EOVERFLOW, "fsmc_identify: candidate buffer too small");
+  }
+  if (count) {
+    // the emission order: by the word at which the reference's ExtendHash reports a match, then by pair key (the
+    // appends of the workgroups arrive in no particular order) -- sorted on the device, fsmc_identify_sort.hip
+    void* sorted = nullptr;
+    hipError_t e = hipMalloc(&sorted, (size_t)count * sizeof(fsmc_candidate));
+    if (e != hipSuccess) {
+      return fail(ctx, FSMC_ENOMEM, std::string("fsmc_identify: hipMalloc failed: ") + hipGetErrorString(e));
+    }
+    e = idSortCandidates(ctx->stream, (const fsmc_candidate*)b.p[5], (fsmc_candidate*)sorted, count, n_haps, n_words);
+    if (e == hipSuccess) {
+      e = hipMemcpy(out, sorted, (size_t)count * sizeof(fsmc_candidate), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(sorted);
+    if (e != hipSuccess) {
+      return fail(ctx, FSMC_EHIP, std::string("fsmc_identify: ordering the candidates failed: ") + hipGetErrorString(e));
+    }
+  }
   return FSMC_OK;
 }
 

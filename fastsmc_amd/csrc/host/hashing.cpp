@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <string>
 
 namespace fsmc_host
 {
@@ -111,6 +112,44 @@ void HashingPrefilter::flush(const int priorTo, const int currentWord, const boo
   }
 }
 
+std::vector<HashingCandidate> HashingPrefilter::runOnDevice(fsmc_ctx* ctx) const
+{
+  std::vector<HashingCandidate> out;
+  if (mNumHaps < 2 || mNumWords == 0) {
+    return out;
+  }
+  std::vector<uint32_t> ids(mNumHaps);
+  for (size_t h = 0; h < mNumHaps; ++h) {
+    ids[h] = mData.globalHapId(static_cast<unsigned>(h));
+  }
+  fsmc_job_window jw{};
+  jw.window_size = static_cast<uint32_t>(mData.windowSize);
+  jw.w_i = static_cast<uint32_t>(mData.w_i);
+  jw.w_j = static_cast<uint32_t>(mData.w_j);
+  jw.last_job = mParams.jobInd == mParams.jobs ? 1 : 0;
+  jw.j_above_diag = mData.is_j_above_diag ? 1 : 0;
+  std::vector<fsmc_candidate> buf(std::max<size_t>(1024, 4 * mNumHaps));
+  size_t n = 0;
+  auto call = [&]() {
+    return fsmc_identify(ctx, mWords.data(), static_cast<uint32_t>(mNumHaps), static_cast<uint32_t>(mNumWords), ids.data(),
+                         &jw, mData.geneticPositions.data(), static_cast<uint32_t>(mData.geneticPositions.size()),
+                         mParams.gap, mParams.skip, mParams.min_m, buf.data(), buf.size(), &n);
+  };
+  int rc = call();
+  if (rc == FSMC_EOVERFLOW) {
+    buf.resize(n);
+    rc = call();
+  }
+  if (rc != FSMC_OK) {
+    throw std::runtime_error(std::string("fsmc_identify: ") + fsmc_last_error(ctx));
+  }
+  out.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    out[i] = HashingCandidate{buf[i].hap_a, buf[i].hap_b, buf[i].from, buf[i].to};
+  }
+  return out;
+}
+
 template <typename Sink> void HashingPrefilter::run(Sink&& sink)
 {
   std::vector<std::pair<uint64_t, unsigned>> order(mNumHaps);
@@ -171,19 +210,35 @@ template <typename Sink> void HashingPrefilter::run(Sink&& sink)
 void runHashing(const Data& data, const DecodingParams& params, HMM& hmm)
 {
   HashingPrefilter pf(data, params);
-  if (hmm.shardWorld() == 1) {
-    pf.run([&](const HashingCandidate& c) { hmm.decodeFromHashing(c.hapA, c.hapB, c.from, c.to); });
-    return;
+  const std::vector<HashingCandidate> all = pf.runOnDevice(hmm.engine());
+  // sharded: every rank runs the identification step and decodes a contiguous range of the resulting batches, so
+  // each batch has the composition -- hence the window -- of a single-device run
+  size_t first = 0, last = all.size();
+  if (hmm.shardWorld() > 1) {
+    const auto B = static_cast<unsigned long long>(hmm.batchSize());
+    const auto [lo, hi] = hmm.shardBatchRange((all.size() + B - 1) / B);
+    first = std::min<size_t>(all.size(), lo * B);
+    last = std::min<size_t>(all.size(), hi * B);
   }
-  // sharded: every rank runs the (cheap, host-side) identification step and decodes a contiguous range of the
-  // resulting batches, so each batch has the composition -- hence the window -- of a single-device run
-  std::vector<HashingCandidate> all;
-  pf.run([&](const HashingCandidate& c) { all.push_back(c); });
-  const auto B = static_cast<unsigned long long>(hmm.batchSize());
-  const auto [lo, hi] = hmm.shardBatchRange((all.size() + B - 1) / B);
-  const size_t first = std::min<size_t>(all.size(), lo * B), last = std::min<size_t>(all.size(), hi * B);
   for (size_t i = first; i < last; ++i) {
     hmm.decodeFromHashing(all[i].hapA, all[i].hapB, all[i].from, all[i].to);
+  }
+}
+
+std::vector<HashingCandidate> hashingCandidatesDevice(const Data& data, const DecodingParams& params, const int device)
+{
+  HashingPrefilter pf(data, params);
+  fsmc_ctx* ctx = nullptr;
+  if (fsmc_ctx_create(device, nullptr, &ctx) != FSMC_OK) {
+    throw std::runtime_error(std::string("cannot open the MI355X engine: ") + fsmc_last_error(nullptr));
+  }
+  try {
+    std::vector<HashingCandidate> out = pf.runOnDevice(ctx);
+    fsmc_ctx_destroy(ctx);
+    return out;
+  } catch (...) {
+    fsmc_ctx_destroy(ctx);
+    throw;
   }
 }
 

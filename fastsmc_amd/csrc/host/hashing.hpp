@@ -54,7 +54,11 @@ class HashingPrefilter
 {
 public:
   HashingPrefilter(const Data& data, const DecodingParams& params);
-  // Streams all complete words; calls sink(candidate) for every match that passes min_m, in emission order.
+  // The candidates in emission order, from the GPU (fsmc_identify: every pair of the job is a lane's state machine
+  // over its word equalities).  This is what FastSMC::run and the sharded runs use.
+  std::vector<HashingCandidate> runOnDevice(fsmc_ctx* ctx) const;
+  // The same stream from the host restatement of the reference's two hash maps (one word at a time): the checker of
+  // the GPU step in tests/ -- no product path calls it.
   template <typename Sink> void run(Sink&& sink);
   unsigned long numWords() const { return mNumWords; }
 
@@ -71,7 +75,9 @@ private:
 };
 
 void runHashing(const Data& data, const DecodingParams& params, HMM& hmm);
-// the candidate list alone, in emission order (tests, and callers that want to shard it across devices)
+// the candidate list alone, in emission order: from the GPU (callers that want to shard it across devices) ...
+std::vector<HashingCandidate> hashingCandidatesDevice(const Data& data, const DecodingParams& params, int device);
+// ... and from the host restatement (tests only)
 std::vector<HashingCandidate> hashingCandidates(const Data& data, const DecodingParams& params);
 
 } // namespace fsmc_host

@@ -429,7 +429,7 @@ void HMM::resetDecoding()
   }
 }
 
-void HMM::ensureEngine()
+fsmc_ctx* HMM::engine()
 {
   if (!mCtx) {
     int rc = fsmc_ctx_create(mParams.gpuDevice, nullptr, &mCtx);
@@ -438,6 +438,12 @@ void HMM::ensureEngine()
       throw std::runtime_error(std::string("cannot open the MI355X decode engine: ") + fsmc_last_error(nullptr));
     }
   }
+  return mCtx;
+}
+
+void HMM::ensureEngine()
+{
+  engine();
   if (!mModel) {
     fsmc_model_desc d{};
     d.K = mPrep.K;

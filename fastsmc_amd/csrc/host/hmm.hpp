@@ -141,6 +141,8 @@ public:
   std::pair<unsigned long long, unsigned long long> shardBatchRange(unsigned long long nBatches) const;
   std::string ibdFileName(int jobs, int jobInd) const;
   int batchSize() const { return mBatchSize; }
+  // the device context of this HMM (opened on first use; the identification step runs on it before any decode)
+  fsmc_ctx* engine();
 
   // keep emitted IBD records in memory as well (tests, benchmarks)
   void setKeepIbdRecords(bool v) { mKeepRecords = v; }

@@ -467,7 +467,20 @@ PYBIND11_MODULE(_pyasmc, m)
           }
           return out;
         },
-        "data"_a, "params"_a, "candidate (hapA, hapB, fromSite, toSite) list of the identification step");
+        "data"_a, "params"_a,
+        "candidate (hapA, hapB, fromSite, toSite) list of the identification step from the HOST restatement of the "
+        "reference's hash maps -- the checker of hashingCandidatesDevice in the tests; FastSMC.run() does not use it");
+  m.def("hashingCandidatesDevice",
+        [](const Data& d, const DecodingParams& p, int device) {
+          py::list out;
+          for (const auto& c : hashingCandidatesDevice(d, p, device)) {
+            out.append(py::make_tuple(c.hapA, c.hapB, c.from, c.to));
+          }
+          return out;
+        },
+        "data"_a, "params"_a, "device"_a = 0,
+        "candidate (hapA, hapB, fromSite, toSite) list of the identification step, computed on the GPU (fsmc_identify) "
+        "-- what FastSMC.run() hands to HMM.decodeFromHashing");
   // StringUtils::stof / stod (StringUtils.cpp:36-44): std::stold narrowed; std::out_of_range -> OverflowError is not a
   // pybind default, so both standard exceptions surface as ValueError subclasses with the C++ type in the message
   m.def("stof", [](const std::string& s) {

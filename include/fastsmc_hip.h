@@ -161,6 +161,32 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags);
  * If cap is too small returns FSMC_EOVERFLOW with *n_out = needed. */
 int fsmc_decode_ibd_fetch(fsmc_ctx* ctx, fsmc_ibd_record* out, size_t cap, size_t* n_out);
 /* Block until the stream is idle. */
+/* ---- identification step (scope row f1; replaces the word loop of FastSMC::run, FastSMC.cpp:118-235, with
+ * HASHING/SeedHash.hpp:29-136, ExtendHash.hpp:26-128, Match.hpp:29-83, Utils.cpp:22-34) ----
+ * Which haplotype pairs of the job share 64-site words over at least min_m centimorgans.  A pair's matching words
+ * are merged into one interval while no more than `gap` words in a row are missing; a word whose number of distinct
+ * values / n_haps is not above `skip` extends every open interval instead of being compared. */
+typedef struct {
+  uint32_t window_size;  /* Data::windowSize (haplotypes per side of a job's square), Data.cpp:62-80 */
+  uint32_t w_i, w_j;     /* 1-based window numbers of the job */
+  int32_t last_job;      /* jobInd == jobs (SeedHash.hpp:97) */
+  int32_t j_above_diag;  /* Data::is_j_above_diag */
+} fsmc_job_window;
+
+typedef struct {
+  uint32_t hap_a, hap_b; /* rows of the word matrix, hap_a < hap_b */
+  uint32_t from, to;     /* first site of the first matching word, last site of the last one (Match.hpp:42-52) */
+  uint32_t flush_word;   /* word at which the reference's ExtendHash would have reported it (n_words: at the end) */
+} fsmc_candidate;
+
+/* words: [n_haps][n_words] host, word w of haplotype h (bit s%64 of word s/64 = allele of site s); global_ids:
+ * [n_haps] haplotype numbers in the whole file (2 * sample line + 0/1); gen_pos: [n_sites] Morgans.  Fills `out` with
+ * the candidates ordered by (flush_word, hap_a * n_haps + hap_b) -- the order in which fastsmc_amd hands them to
+ * HMM::decodeFromHashing.  FSMC_EOVERFLOW: cap too small, *n_out = the number of candidates. */
+int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_t n_words, const uint32_t* global_ids,
+                  const fsmc_job_window* job, const float* gen_pos, uint32_t n_sites, int32_t gap, float skip,
+                  float min_m, fsmc_candidate* out, size_t cap, size_t* n_out);
+
 int fsmc_sync(fsmc_ctx* ctx);
 /* Device time (ms, hipEvent) of the last decode launch's kernel(s); valid after a sync/fetch. */
 int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms);

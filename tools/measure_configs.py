@@ -7,7 +7,9 @@ never as bench.py's `value`):
   hashing            FastSMC.run() end to end with the hashing pre-filter on, C2-sized files (parse + identify + decode +
                      write)
   short              the IBD decode alone on 60 000 hashing-style batches (32 pairs, 320-5504-site windows): the C5 regime
-Prints one JSON object per measurement.  Usage: python tools/measure_configs.py [c1 k256 k192 k128 k100 hashing short]"""
+  identify           the identification step alone (fsmc_identify) on the C2 cohort (1000 x 50 000) and on a C3-shaped
+                     one (10 000 x 100 000): pair-words/s of the three kernels, with the host restatement beside it
+Prints one JSON object per measurement.  Usage: python tools/measure_configs.py [c1 k256 k192 k128 k100 hashing short identify]"""
 from __future__ import annotations
 
 import copy
@@ -233,8 +235,44 @@ def short_windows():
     ctx.close()
 
 
+def identify():
+    """fsmc_identify: every pair of the cohort against every complete word (passes 1 and 3 each do n^2/2 * words
+    64-bit compares out of LDS).  LDS traffic per pair-word: 10 bytes (five 8-byte reads serve four pairs)."""
+    for n_hap, S in ((1000, 50000), (10000, 100000)):
+        haps = (synth.make_haps if n_hap <= 1000 else synth.make_haps_blocked)(n_hap, S, seed=1234)
+        W = S // 64
+        words = np.packbits(haps.alleles[:, :W * 64].reshape(n_hap, W, 64), axis=2,
+                            bitorder="little").view(np.uint64).reshape(n_hap, W)
+        gen = (haps.cm / 100.0).astype(np.float32)
+        ids = np.arange(n_hap, dtype=np.uint32)
+        ctx = capi.Context(0)
+        rec = ctx.identify(words, ids, gen, min_m=1.0)  # warm-up (and the buffer size)
+        t0 = time.perf_counter()
+        rec = ctx.identify(words, ids, gen, min_m=1.0)
+        dt = time.perf_counter() - t0
+        ms = ctx.last_kernel_ms()
+        ctx.close()
+        pair_words = n_hap * (n_hap - 1) / 2 * W
+        out = {"config": "identify", "haplotypes": n_hap, "sites": S, "words": W, "pairs": n_hap * (n_hap - 1) // 2,
+               "candidates": int(rec.size), "kernels_ms": ms, "call_s": dt,
+               "pair_words_per_s_two_passes": 2 * pair_words / (ms * 1e-3),
+               "lds_GBps": 2 * pair_words * 10 / (ms * 1e-3) / 1e9, "lds_peak_GBps": 128 * 256 * 2.4}
+        if n_hap <= 1000:
+            data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
+            p = api.DecodingParams()
+            p.FastSMC = True
+            p.hashing = True
+            p.min_m = 1.0
+            t0 = time.perf_counter()
+            host = api.hashingCandidates(data, p)
+            out["host_restatement_s"] = time.perf_counter() - t0
+            out["host_equal"] = [tuple(c) for c in host] == [(int(r["hap_a"]), int(r["hap_b"]), int(r["from"]), int(r["to"]))
+                                                            for r in rec]
+        print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
         {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "hashing": hashing,
-         "short": short_windows, "run_c2": run_c2}[w]()
+         "short": short_windows, "run_c2": run_c2, "identify": identify}[w]()
