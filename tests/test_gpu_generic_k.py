@@ -102,7 +102,10 @@ def test_too_many_states_is_rejected():
     ctx = capi.Context(0)
     import copy
     big = copy.copy(pm)
-    big.K = 300
+    big.K = 300  # every array widened to 300 states: the shapes are consistent, the C side refuses the size
+    pad = lambda a: np.pad(np.asarray(a, np.float32), [(0, 0)] * (np.ndim(a) - 1) + [(0, 300 - pm.K)])  # noqa: E731
+    for f in ("pi", "col_ratios", "exp_times", "D", "B", "U", "RR", "e1", "e0m1", "e2m0"):
+        setattr(big, f, pad(getattr(pm, f)))
     with pytest.raises(capi.FsmcError):
         ctx.create_model(big)
     ctx.close()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box: the side measurements of a round that are kept under profiles/ next to the headline profile
 # (tools/profile_bench.sh): C3 single-GPU point, C4 at size with rocprofv3 kernel stats + traffic, the short-window
-# (hashing) regime with kernel stats, the padded family members, the product path end to end.
+# (hashing) regime with kernel stats, the padded family members, the identification step with kernel stats, the product
+# path end to end (with and without the hashing pre-filter).
 # Usage: tools/measure_round.sh <tag>
 set -u
 TAG=$1
@@ -21,6 +22,10 @@ for K in 16 32 48 50 64 80 96 100 112 128 192; do
   python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --states $K > $OUT/fam.json 2>/dev/null && cat $OUT/fam.json >> $OUT/family.jsonl
 done
 echo "family done"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/identify_trace -- python3 $GRAFT_REPO_ROOT/tools/measure_configs.py identify > $OUT/identify.jsonl 2> $OUT/identify.err )
+cp $(find $OUT/identify_trace -name "*kernel_stats.csv" | head -1) $OUT/identify_kernel_stats.csv 2>/dev/null
+python3 tools/measure_configs.py hashing > $OUT/hashing.json 2> $OUT/hashing.err
+echo "identify done"
 python3 tools/measure_configs.py run_c2 > $OUT/run_c2.json 2> $OUT/run_c2.err
 python3 tools/measure_configs.py c1 > $OUT/c1.json 2> $OUT/c1.err
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
