@@ -4,6 +4,8 @@
   tools/stamp_profiles.py traffic <profile_dir> <tag>   tools/profile_bench.sh output -> profiles/<tag>_traffic.json,
                                                          <tag>_kernel_stats.csv, <tag>_rocprofv3_summary.json
   tools/stamp_profiles.py c3n1 <bench_json> <tag>       `bench.py --workload c3` line -> profiles/<tag>_c3_n1.json
+  tools/stamp_profiles.py round <round_dir> <tag>       tools/measure_round.sh output (gpurun_out/round_<tag>, with the C4
+                                                         profile in gpurun_out/profile_<tag>_c4) -> profiles/<tag>_*
 
 Every file carries `lib_hash` = the hash of the HIP library's sources (fastsmc_amd.build.hip_source_hash()); bench.py
 reports a committed measurement only when that hash is the current one."""
@@ -57,5 +59,38 @@ def c3n1(src: str, tag: str) -> None:
     print(key, out["value"])
 
 
+def round_files(src: str, tag: str) -> None:
+    import shutil
+
+    h = hip_source_hash()
+    prof = os.path.join(ROOT, "profiles")
+    c4 = os.path.join(os.path.dirname(os.path.abspath(src)), f"profile_{tag}_c4")
+    summ = json.load(open(os.path.join(c4, "summary.json")))
+    line = json.loads(open(os.path.join(c4, "bench_under_trace.json")).read().strip().splitlines()[-1])
+    assert line["config"]["lib_hash"] == h, "the C4 profile was taken with another build of the library"
+    stats = summ["kernel_stats_csv"]
+    kern = [ln for ln in stats.splitlines() if "decode_kernel" in ln][0]
+    avg_ns = float(kern.split('",')[1].split(",")[2])
+    pmc = summ["pmc_per_launch"]
+    hbm = (2 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+    alg = line["roofline"]["algorithmic_bytes_per_launch"]
+    out = {"workload": line["config"]["workload"], "kernel": kern.split('",')[0].strip('"'),
+           "kernel_avg_ns_rocprofv3": avg_ns, "kernel_ms_hip_events_same_run": line["roofline"]["kernel_ms"],
+           "FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_per_launch": pmc["WRITE_SIZE"]["mean"],
+           "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
+           "frac_algorithmic_from_rocprof_avg": alg / (avg_ns * 1e-9) / 8e12,
+           "frac_measured_bytes": hbm / (avg_ns * 1e-9) / 8e12, "lib_hash": h, "bench_line": line}
+    json.dump(out, open(os.path.join(prof, f"{tag}_c4_at_size.json"), "w"), indent=1)
+    open(os.path.join(prof, f"{tag}_c4_at_size_kernel_stats.csv"), "w").write(stats)
+    for a, b in (("c4_reduced.json", "c4_reduced_600x3000.json"), ("family.jsonl", "family_members_c2_shape.jsonl"),
+                 ("short.json", "short_windows.json"), ("short_kernel_stats.csv", "short_windows_kernel_stats.csv"),
+                 ("run_c2.json", "run_c2_product_path.json"), ("bench_default.json", "bench_default.json"),
+                 ("c1.json", "c1_shape.jsonl"), ("identify.jsonl", "identify.jsonl"),
+                 ("identify_kernel_stats.csv", "identify_kernel_stats.csv"),
+                 ("hashing.json", "hashing_c2_files_end_to_end.json")):
+        shutil.copy(os.path.join(src, a), os.path.join(prof, f"{tag}_{b}"))
+    c3n1(os.path.join(src, "c3_n1.json"), tag)
+
+
 if __name__ == "__main__":
-    {"traffic": traffic, "c3n1": c3n1}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {"traffic": traffic, "c3n1": c3n1, "round": round_files}[sys.argv[1]](sys.argv[2], sys.argv[3])
