@@ -287,6 +287,28 @@ bool quarterLanes(int mode, const fsmc_model* m)
          (m->KP == 192 || m->KP == 256);
 }
 
+// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): the IBD and dump consumers of the
+// same models.  FSMC_WIDE_Q4 in the environment keeps the four-lanes-per-pair kernel (A/B measurements, tests).
+bool waveGroups(int mode, const fsmc_model* m)
+{
+  return quarterLanes(mode, m) && m->K > 128 && (mode == kModeIbd || mode == kModeDump) &&
+         std::getenv("FSMC_WIDE_Q4") == nullptr;
+}
+
+template <int KH> KernelFn pickWaveGroupKernel(int mode, bool track)
+{
+  if (mode == kModeIbd) {
+    return track ? decode_kernel_w2<KH, kModeIbd, true> : decode_kernel_w2<KH, kModeIbd, false>;
+  }
+  return decode_kernel_w2<KH, kModeDump, false>;
+}
+
+// threads of a workgroup of the kernel pickKernel returns for this mode and model
+unsigned blockThreads(int mode, const fsmc_model* m)
+{
+  return waveGroups(mode, m) ? (unsigned)(kW2NW * kWave) : (unsigned)kWave;
+}
+
 template <int KQ> KernelFn pickQuarterKernel(int mode, bool track)
 {
   if (mode == kModeIbd) {
@@ -300,6 +322,13 @@ template <int KQ> KernelFn pickQuarterKernel(int mode, bool track)
 
 KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false)
 {
+  if (waveGroups(mode, m)) {
+    if (mode == kModeIbd) {
+      m->ctx->lastStride = 1;
+    }
+    m->ctx->lastMember = 1000 + m->KP / kW2NW; // 1048 / 1064: four waves per group, 48 / 64 states per wave
+    return m->KP == 192 ? pickWaveGroupKernel<48>(mode, track) : pickWaveGroupKernel<64>(mode, track);
+  }
   if (quarterLanes(mode, m)) {
     if (mode == kModeIbd) {
       m->ctx->lastStride = 1;
@@ -355,7 +384,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
 {
   const std::vector<fsmc_group>& list = items ? *items : ctx->hGroups;
   int blocksPerCU = 0;
-  FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fn, kWave, 0));
+  FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fn, (int)blockThreads(mode, m), 0));
   if (blocksPerCU < 1) {
     blocksPerCU = 1;
   }
@@ -368,7 +397,8 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
       blocksPerCU = v;
     }
   }
-  const bool q4 = quarterLanes(mode, m); // a wave takes a quarter of a group and holds 64 states per lane
+  const bool w2 = waveGroups(mode, m);          // a workgroup of four waves takes a group, lane = pair
+  const bool q4 = !w2 && quarterLanes(mode, m); // a wave takes a quarter of a group and holds 64 states per lane
   size_t slots = (size_t)ctx->nCU * blocksPerCU;
   slots = std::min(slots, q4 ? 4 * list.size() : list.size());
   if (slots < 1) {
@@ -381,7 +411,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   }
   // float4 per lane of a stored K-vector: q4 lanes hold KP/4 states; a padded family member stores its ghosts too
   const int member = familyMember(m);
-  const size_t K4 = q4 ? (size_t)m->KP / 16 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
+  const size_t K4 = w2 ? (size_t)m->KP / 4 : q4 ? (size_t)m->KP / 16 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / share;
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
@@ -498,11 +528,11 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.recCap = (unsigned)ctx->recCap;
 }
 
-int launch(fsmc_ctx* ctx, KernelFn fn, const KParams& p, int slots)
+int launch(fsmc_ctx* ctx, KernelFn fn, const KParams& p, int slots, unsigned threads = kWave)
 {
   FSMC_HIP(ctx, hipMemsetAsync(ctx->dCounters, 0, 4 * sizeof(unsigned), ctx->stream));
   FSMC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(fn, dim3((unsigned)slots), dim3(kWave), 0, ctx->stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)slots), dim3(threads), 0, ctx->stream, p);
   FSMC_HIP(ctx, hipGetLastError());
   FSMC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->timed = true;
@@ -1139,7 +1169,8 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     }
   }
   rc = beside ? launchBeside(ctx, fn, p, plan.slots, fnDual, pDual, planDual.slots)
-              : q.dual ? launch(ctx, fnDual, pDual, planDual.slots) : launch(ctx, fn, p, plan.slots);
+              : q.dual ? launch(ctx, fnDual, pDual, planDual.slots)
+                       : launch(ctx, fn, p, plan.slots, blockThreads(kModeIbd, m));
   if (rc != FSMC_OK) {
     return rc;
   }
@@ -1377,7 +1408,7 @@ int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_
   }
   FSMC_HIP(ctx, hipMemcpyAsync(ctx->aux.p, offsets.data(), offsets.size() * sizeof(size_t), hipMemcpyHostToDevice,
                                ctx->stream));
-  if (quarterLanes(kModeDump, m)) {
+  if (quarterLanes(kModeDump, m) && !waveGroups(kModeDump, m)) {
     // quarters of a group that hold no pair are skipped by the kernel: their lanes must read as zero
     FSMC_HIP(ctx, hipMemsetAsync(ctx->out.p, 0, total * sizeof(float), ctx->stream));
   }
@@ -1385,7 +1416,7 @@ int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_
   fillParams(ctx, m, plan, 0, p);
   p.dumpOut = (float*)ctx->out.p;
   p.dumpOffsets = (const size_t*)ctx->aux.p;
-  rc = launch(ctx, fn, p, plan.slots);
+  rc = launch(ctx, fn, p, plan.slots, blockThreads(kModeDump, m));
   if (rc != FSMC_OK) {
     return rc;
   }

@@ -15,6 +15,7 @@
 
 #include "fsmc_kernels.h"
 #include "fsmc_kernels_q4.h"
+#include "fsmc_kernels_w2.h"
 
 namespace fsmc
 {
@@ -56,14 +57,22 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_DEFINE_KT_DUAL(KT)                                                                                        \
   template __global__ void decode_kernel<KT, kModeIbd, true, false, false, true>(const KParams);                     \
   template __global__ void decode_kernel<KT, kModeIbd, false, false, false, true>(const KParams);
+// four waves per group, lane = pair (fsmc_kernels_w2.h): 128 < K <= 256, KH = 48, 64 states per wave
+#define FSMC_W2_KERNELS(X, KH)                                                                                         \
+  X(KH, kModeIbd, true)                                                                                                \
+  X(KH, kModeIbd, false)                                                                                               \
+  X(KH, kModeDump, false)
+#define FSMC_DECLARE_W2(KH, MODE, TRACK) extern template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
+#define FSMC_DEFINE_W2(KH, MODE, TRACK) template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
 #define FSMC_DECLARE_Q4(KQ, MODE, TRACK) extern template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 #define FSMC_DEFINE_Q4(KQ, MODE, TRACK) template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 
 // every member of the library (build.py compiles fsmc_inst.hip once for each entry of these two lists)
 #define FSMC_ALL_KT(Y) Y(0) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80) Y(96) Y(112) Y(128)
 #define FSMC_ALL_Q4(Y) Y(48) Y(64)
+#define FSMC_ALL_W2(Y) Y(48) Y(64)
 
-#if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_Q4)
+#if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_Q4) && !defined(FSMC_INSTANCE_W2)
 #define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)
 FSMC_ALL_KT(FSMC_DECLARE_MEMBER)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 16)
@@ -85,6 +94,8 @@ FSMC_DECLARE_KT_DUAL(112)
 FSMC_DECLARE_KT_DUAL(128)
 #define FSMC_DECLARE_Q4_MEMBER(KQ) FSMC_Q4_KERNELS(FSMC_DECLARE_Q4, KQ)
 FSMC_ALL_Q4(FSMC_DECLARE_Q4_MEMBER)
+#define FSMC_DECLARE_W2_MEMBER(KH) FSMC_W2_KERNELS(FSMC_DECLARE_W2, KH)
+FSMC_ALL_W2(FSMC_DECLARE_W2_MEMBER)
 #endif
 
 } // namespace fsmc

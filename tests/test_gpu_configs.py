@@ -96,7 +96,7 @@ def test_c3_shard_shape_100k_sites():
 
 
 def test_c4_256_states_200k_sites_chunked_wide_model_kernel():
-    _whole_sequence_case(n_hap=128, S=200000, K=256, n_pairs=2048, n_sample=8, want_member=-64, time=200)
+    _whole_sequence_case(n_hap=128, S=200000, K=256, n_pairs=2048, n_sample=8, want_member=1064, time=200)
 
 
 def test_c1_reference_example_data_job_7_of_9(tmp_path):

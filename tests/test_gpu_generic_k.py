@@ -3,6 +3,8 @@ the next family member (16, 32, 48, 64, 80 states with two waves per SIMD, 96, 1
 ghosts -- K = 2, 5, 16 exactly, 17, 33, 50, 64 exactly, 65, 70, 80 exactly, 81, 100, 128 exactly); 128 < K <= 256 the
 wide-model kernel (four lanes per pair, 48 / 64 states per lane, ghost-padded -- K = 130, 192 exactly, 200, 256
 exactly), whose sums over pairs still come from the runtime-K kernel.  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -22,12 +24,16 @@ def _problem(K, n_hap=64, S=200, seed=11):
     return pm, bits, folded
 
 
-def _member(K):
+def _member(K, consumer="ibd"):
+    """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; beyond, the four-waves-per-group
+    kernel (1000 + states per wave) for the IBD and dump consumers and the four-lanes-per-pair kernel (-states per lane)
+    for the per-pair consumer -- or for all three with FSMC_WIDE_Q4 in the environment."""
     if K == 69:
         return 69
     if K <= 128:
         return (K + 15) // 16 * 16
-    return -(48 if K <= 192 else 64)
+    kq = 48 if K <= 192 else 64
+    return -kq if consumer == "per_pair" or os.environ.get("FSMC_WIDE_Q4") else 1000 + kq
 
 
 def _stride(K):
@@ -61,7 +67,7 @@ def test_generic_kernel_matches_oracle(K):
     wpost, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
     np.testing.assert_array_equal(post, wpost)
     mean, mp = ctx.decode_per_pair(model, pm.exp_times)
-    assert ctx.last_kernel() == _member(K)
+    assert ctx.last_kernel() == _member(K, "per_pair")
     wmean, wmap, _ = O.per_pair_output(pm, wpost, 64)
     np.testing.assert_array_equal(mean, wmean)
     np.testing.assert_array_equal(mp, wmap)
@@ -95,6 +101,14 @@ def test_padded_members_stride_and_chunking(K):
                                   ("post_mean", "postMean"), ("map", "map")):
                 np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f"{f_got} stride {stride} chunk {chunk}")
             ctx.close()
+
+
+@pytest.mark.parametrize("K", [130, 192, 200, 256])
+def test_wide_models_on_the_four_lanes_kernel_too(K, monkeypatch):
+    """FSMC_WIDE_Q4 keeps the four-lanes-per-pair kernel for the IBD and dump consumers of 128 < K <= 256 (the kernel the
+    per-pair consumer always uses): same bits."""
+    monkeypatch.setenv("FSMC_WIDE_Q4", "1")
+    test_generic_kernel_matches_oracle(K)
 
 
 def test_too_many_states_is_rejected():
