@@ -287,18 +287,21 @@ bool quarterLanes(int mode, const fsmc_model* m)
          (m->KP == 192 || m->KP == 256);
 }
 
-// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): the IBD and dump consumers of the
-// same models.  FSMC_WIDE_Q4 in the environment keeps the four-lanes-per-pair kernel (A/B measurements, tests).
+// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): the IBD, dump and sums consumers
+// of the same models.  FSMC_WIDE_Q4 in the environment keeps the four-lanes-per-pair kernel (A/B measurements, tests).
 bool waveGroups(int mode, const fsmc_model* m)
 {
-  return quarterLanes(mode, m) && m->K > 128 && (mode == kModeIbd || mode == kModeDump) &&
-         std::getenv("FSMC_WIDE_Q4") == nullptr;
+  return familyMember(m) == 0 && m->K > 128 && m->K <= 256 && !m->sequence && (m->KP == 192 || m->KP == 256) &&
+         (mode == kModeIbd || mode == kModeDump || mode == kModeSums) && std::getenv("FSMC_WIDE_Q4") == nullptr;
 }
 
 template <int KH> KernelFn pickWaveGroupKernel(int mode, bool track)
 {
   if (mode == kModeIbd) {
     return track ? decode_kernel_w2<KH, kModeIbd, true> : decode_kernel_w2<KH, kModeIbd, false>;
+  }
+  if (mode == kModeSums) {
+    return decode_kernel_w2<KH, kModeSums, false>;
   }
   return decode_kernel_w2<KH, kModeDump, false>;
 }
@@ -1532,7 +1535,7 @@ int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sum
   for (size_t base = 0; base < ctx->nGroups; base += slots) {
     const size_t n = std::min(slots, ctx->nGroups - base);
     p.groupBase = (int)base;
-    rc = launch(ctx, fn, p, (int)n);
+    rc = launch(ctx, fn, p, (int)n, blockThreads(kModeSums, m));
     if (rc != FSMC_OK) {
       return rc;
     }

@@ -61,7 +61,8 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_W2_KERNELS(X, KH)                                                                                         \
   X(KH, kModeIbd, true)                                                                                                \
   X(KH, kModeIbd, false)                                                                                               \
-  X(KH, kModeDump, false)
+  X(KH, kModeDump, false)                                                                                              \
+  X(KH, kModeSums, false)
 #define FSMC_DECLARE_W2(KH, MODE, TRACK) extern template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
 #define FSMC_DEFINE_W2(KH, MODE, TRACK) template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
 #define FSMC_DECLARE_Q4(KQ, MODE, TRACK) extern template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);

@@ -40,6 +40,20 @@ __device__ __forceinline__ void w2Barrier()
 {
   FSMC_GCN_ASM("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// The barriers between the phases of a step / between the partial sums.  -DFSMC_W2_DIAG_NO_PHASE_BARRIERS and
+// -DFSMC_W2_DIAG_NO_SUM_BARRIERS are timing experiments only (results are wrong): what the hand-overs cost.
+__device__ __forceinline__ void w2PhaseBarrier()
+{
+#if !defined(FSMC_W2_DIAG_NO_PHASE_BARRIERS)
+  w2Barrier();
+#endif
+}
+__device__ __forceinline__ void w2SumBarrier()
+{
+#if !defined(FSMC_W2_DIAG_NO_SUM_BARRIERS)
+  w2Barrier();
+#endif
+}
 
 struct W2Ctx {
   float* mail;  // [kW2Mail][64] in LDS, shared by the waves of the group
@@ -63,7 +77,11 @@ __device__ __forceinline__ float w2OrderedTotal(const W2Ctx& cx, const float (&v
       }
       cx.mail[(row + ph) * kWave + cx.lane] = s;
     }
-    w2Barrier();
+    if (ph == kW2NW - 1) {
+      w2Barrier();
+    } else {
+      w2SumBarrier();
+    }
   }
   return cx.mail[(row + kW2NW - 1) * kWave + cx.lane];
 }
@@ -253,7 +271,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         descending(tIn, buIn, true);
       }
     }
-    w2Barrier();
+    w2PhaseBarrier();
   }
   const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
   w2Scale<KH>(b, w, total);
@@ -420,7 +438,7 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
         finish(cIn);
       }
     }
-    w2Barrier();
+    w2PhaseBarrier();
   }
   const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
   w2Scale<KH>(a, w, total);
@@ -442,7 +460,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 template <int KH, int MODE, bool TRACK>
 __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KParams p)
 {
-  static_assert(MODE == kModeIbd || MODE == kModeDump, "the two-wave kernel has the IBD and the dump consumer");
+  static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums,
+                "the wave-group kernel has the IBD, the dump and the sums-over-pairs consumer");
   constexpr int KP = kW2NW * KH;
   constexpr int K4H = KH / 4;        // float4 per lane of this wave's part of a K-vector
   constexpr int E4H = 3 * K4H;       // float4 of one site's emission values of this wave's states (three classes)
@@ -452,6 +471,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
   __shared__ float mailLds[kW2Mail * kWave];
   __shared__ float4 piLds[KP / 4];   // initialStateProb, zero padded
   __shared__ unsigned groupLds;
+  __shared__ unsigned char clsLds[kW2NW][kWave]; // kModeSums: observation class of every pair at the current site
 
   const int lane = threadIdx.x & (kWave - 1);
   // (wave-uniform BY CONSTRUCTION: as a scalar the compiler branches on it instead of predicating both roles)
@@ -476,13 +496,21 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
   const cfloat_p tCR = (cfloat_p)p.cR;
   const cfloat_p ghostMask = (cfloat_p)p.ghostMask;
 
-  for (;;) {
-    if (threadIdx.x == 0) {
-      groupLds = atomicAdd(&p.counters[p.groupBase], 1u);
+  for (unsigned round = 0;; ++round) {
+    unsigned g;
+    if (MODE == kModeSums) {
+      // one group per workgroup and launch: workgroup i writes the batch sums of group groupBase + i into plane i, and
+      // the host adds the planes to the accumulator one after the other -- the reference's order, batch by batch
+      // (HMM.cpp:1054-1073)
+      g = round == 0 ? (unsigned)p.groupBase + blockIdx.x : (unsigned)p.nGroups;
+    } else {
+      if (threadIdx.x == 0) {
+        groupLds = atomicAdd(&p.counters[p.groupBase], 1u);
+      }
+      w2Barrier();
+      g = __builtin_amdgcn_readfirstlane(groupLds);
+      w2Barrier(); // (groupLds is rewritten by the next round only after every wave has read it)
     }
-    w2Barrier();
-    const unsigned g = __builtin_amdgcn_readfirstlane(groupLds);
-    w2Barrier(); // (groupLds is rewritten by the next round only after both waves have read it)
     if (g >= (unsigned)p.nGroups) {
       break;
     }
@@ -742,11 +770,59 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
         const float cq = 1.0f / sumq;
         // every read of the landing zone and of this site's ring slot has returned (the barriers above waited for
         // lgkmcnt(0)): request the next site's beta row and the rows of site pos + 2
-        if (pos + 1 < hi) {
+        if (MODE != kModeSums && pos + 1 < hi) {
           fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
         }
         if (pos + 2 < hi) {
           stageEmis(pos + 2);
+        }
+
+        if (MODE == kModeSums) {
+          // HMM::augmentSumOverPairs (HMM.cpp:1052-1081): per site and state, the batch's posteriors are summed over
+          // pairs in batch order (local fp32 sum from 0.f).  Every wave transposes the tile of ITS states through its
+          // landing zone (64 x 64 floats, row k rotated by k lanes: conflict-free both ways); lane j then owns state j.
+          float* const tile = reinterpret_cast<float*>(&betaLds[h][0]);
+#pragma unroll
+          for (int k = 0; k < KH; ++k) {
+            tile[k * kWave + ((lane + k) & (kWave - 1))] = w[k] * cq;
+          }
+          if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+            clsLds[h][lane] = (unsigned char)c;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          waitLgkm0();
+          __builtin_amdgcn_wave_barrier();
+          const int state = h * KH + lane;
+          if (lane < KH && state < K) {
+            float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
+            for (int v = 0; v < nPairsInGroup; ++v) {
+              const float q = tile[lane * kWave + ((v + lane) & (kWave - 1))];
+              s = s + q;
+              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                const int cv = clsLds[h][v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
+                if (cv == 2) {
+                  s11 = s11 + q;
+                } else if (cv == 1) {
+                  s00 = s00 + q;
+                } else {
+                  s01 = s01 + q;
+                }
+              }
+            }
+            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + state;
+            if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
+            if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+              acc[p.sumsPlane] = s00;
+              acc[2 * p.sumsPlane] = s01;
+              acc[3 * p.sumsPlane] = s11;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          waitLgkm0();
+          __builtin_amdgcn_wave_barrier();
+          if (pos + 1 < hi) {
+            fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
+          }
         }
 
         if (MODE == kModeDump) {

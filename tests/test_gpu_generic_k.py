@@ -1,8 +1,9 @@
 """Models other than K = 69 against the oracle, all output modes.  K <= 80 runs the lane-per-pair kernel compiled for
 the next family member (16, 32, 48, 64, 80 states with two waves per SIMD, 96, 112, 128 with one; the padding states are
 ghosts -- K = 2, 5, 16 exactly, 17, 33, 50, 64 exactly, 65, 70, 80 exactly, 81, 100, 128 exactly); 128 < K <= 256 the
-wide-model kernel (four lanes per pair, 48 / 64 states per lane, ghost-padded -- K = 130, 192 exactly, 200, 256
-exactly), whose sums over pairs still come from the runtime-K kernel.  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
+wide-model kernels, ghost-padded (K = 130, 192 exactly, 200, 256 exactly): four waves per group with lane = pair for
+the IBD, dump and sums consumers, four lanes per pair for the per-pair consumer (and for everything but the sums with
+FSMC_WIDE_Q4 in the environment, when the sums come from the runtime-K kernel).  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
 import os
 
 import numpy as np
@@ -72,10 +73,16 @@ def test_generic_kernel_matches_oracle(K):
     np.testing.assert_array_equal(mean, wmean)
     np.testing.assert_array_equal(mp, wmap)
     s, _ = ctx.decode_sums(model)  # (K = 256 included: the transposition tile is sized for it)
-    assert ctx.last_kernel() == (_member(K) if K <= 128 else 0)
+    assert ctx.last_kernel() == (0 if K > 128 and os.environ.get("FSMC_WIDE_Q4") else _member(K))
     wsum = np.zeros((pm.S, pm.K), np.float32)
     O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
     np.testing.assert_array_equal(s, wsum)
+    if K in (5, 100, 200, 256):  # the 00 / 01 / 11 split in one member of each kernel
+        s2, mm = ctx.decode_sums(model, major_minor=True)
+        want = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
+        O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, want[0], want[1], want[2], want[3])
+        for got, w in zip((s2, *mm), want):
+            np.testing.assert_array_equal(got, w)
     ctx.close()
 
 

@@ -19,6 +19,10 @@ done
 for K in 48 64; do
   hipcc $FLAGS "$@" -DFSMC_INSTANCE_Q4=$K -o $OBJ/q4_$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
 done
+for K in 48 64; do
+  hipcc $FLAGS "$@" -DFSMC_INSTANCE_W2=$K -o $OBJ/w2_$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
+done
+hipcc $FLAGS -o $OBJ/idsort.o $ROOT/fastsmc_amd/csrc/fsmc_identify_sort.hip & PIDS="$PIDS $!"
 for P in $PIDS; do wait $P; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib$NAME.so $OBJ/*.o
 rm -rf $OBJ
