@@ -110,6 +110,36 @@ def test_padded_members_stride_and_chunking(K):
             ctx.close()
 
 
+@pytest.mark.parametrize("K,time", [(256, 9000), (256, 20000), (200, 20000), (150, 20000)])
+def test_wide_model_scan_thresholds_that_reach_the_upper_waves(K, time):
+    """The IBD scan sums the posterior of the states below the time threshold in state order: with the four-waves-per-
+    group kernel that sum starts in wave 0 and continues in as many waves as the threshold reaches (here two, three
+    and four of them; the other tests of this file stay inside wave 0)."""
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(64, 200, seed=K + 1, cm_per_mb=25.0, switch_per_cm=0.6)
+    bits, derived, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    pm = O.prepare_model(tables, (haps.cm / 100.0).astype(np.float32), haps.bp, derived, 64, time=time)
+    kh = 48 if K <= 192 else 64
+    assert pm.state_threshold > kh
+    pairs = O.enumerate_all_pairs(32)[:80]
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    want = O.decode_pairs_ibd(pm, folded, pairs, batch_size=64)
+    for flags in (capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP, 0):
+        got = ctx.decode_ibd(model, pr, capi.whole_sequence_groups(len(pairs), pm.S), flags)
+        assert ctx.last_kernel() == 1000 + kh
+        assert got.size == want.size and got.size > 0
+        for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob")):
+            np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f_got)
+        if flags:
+            np.testing.assert_array_equal(got["post_mean"], want["postMean"])
+            np.testing.assert_array_equal(got["map"], want["map"])
+    ctx.close()
+
+
 @pytest.mark.parametrize("K", [130, 192, 200, 256])
 def test_wide_models_on_the_four_lanes_kernel_too(K, monkeypatch):
     """FSMC_WIDE_Q4 keeps the four-lanes-per-pair kernel for the IBD and dump consumers of 128 < K <= 256 (the kernel the
