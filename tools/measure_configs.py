@@ -98,6 +98,41 @@ def k256(K=256):
     ctx.close()
 
 
+def seq(K=69):
+    """Sequence mode (decodingSequence, scope row f4): two steps per site; 600 haplotypes x 3000 sites, all pairs."""
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(600, 3000, seed=1234, cm_per_mb=1.2, bp_per_site=2500, switch_per_cm=2.0)
+    data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
+    dq = api.decoding_quantities_from_tables(tables)
+    p = api.DecodingParams()
+    p.FastSMC = True
+    p.decodingModeString = "sequence"
+    p.foldData = True
+    p.usingCSFS = True
+    p.batchSize = 32
+    p.time = 50
+    p.noConditionalAgeEstimates = True
+    p.doPerPairPosteriorMean = True
+    p.doPerPairMAP = True
+    p.useKnownSeed = True
+    p.hashing = False
+    hmm = api.HMM(data, dq, p)
+    pm = api.PreparedModelView(hmm.preparedModel())
+    pairs = all_pairs(300)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(data.packed_bits(), pm.S)
+    pr = pairs.view(capi.PAIR_DTYPE).reshape(-1)
+    ctx.upload_worklist(pr, capi.whole_sequence_groups(len(pr), pm.S, batch=64))
+    dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1], reps=1)
+    # two transition steps per site: the algorithmic bytes of the contract (one alpha row stored and read per site) stay
+    print(json.dumps({"config": f"seq_k{K}_ibd", "pairs": len(pr), "sites": pm.S, "K": pm.K, "seconds": dt,
+                      "kernel_member": ctx.last_kernel(), "pair_sites_per_s": len(pr) * pm.S / dt,
+                      "kernel_ms": ctx.last_kernel_ms(),
+                      "algorithmic_GBps": len(pr) * pm.S * (8 * pm.K + 0.25) / dt / 1e9, "records": int(rec.size)}))
+    ctx.close()
+
+
 def hashing():
     from oracle import oracle as O  # only for the table-key selection helper used by the tests as well
 
@@ -275,4 +310,4 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
         {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "hashing": hashing,
-         "short": short_windows, "run_c2": run_c2, "identify": identify}[w]()
+         "short": short_windows, "run_c2": run_c2, "identify": identify, "seq": seq, "seq100": lambda: seq(100)}[w]()
