@@ -20,6 +20,8 @@
 // upper half, whose backward step multiplies by the 1/0 mask row).
 #pragma once
 
+#include <type_traits>
+
 #include "fsmc_kernels.h"
 
 namespace fsmc
@@ -31,6 +33,7 @@ constexpr int kW2RowT = 0, kW2RowBU = 3, kW2RowBL = 6, kW2RowC = 0, kW2RowAU = 3
 constexpr int kW2RowStep = 9, kW2RowComb = 13, kW2RowScan = 17, kW2RowLevel = 21;
 constexpr int kW2Mail = 23;
 constexpr int kWBF = 8;    // ... and of the forward pass (four tables at a time)
+constexpr int kWBWide = 8;  // ... of the passes with two operand rows (16-state blocks measured 4 % slower at 64 states per wave: spills)
 constexpr int kWB = 8;     // states per operand block of the backward passes here (two waves' roles in one kernel leave
                            // fewer scalar registers than fsmc_kernels.h has: 16-state blocks were spilled in flight)
 
@@ -107,9 +110,8 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
                                              const float4* e, cfloat_p ghostMask)
 {
   constexpr int KP = kW2NW * KH;
-  constexpr int NB = KH / kWB;
-  static_assert(KH % kWB == 0, "whole operand blocks");
-  typedef typename SV<kWB>::T SVec;
+  constexpr int kLines = KH / 16; // 64-byte lines of this wave's part of a table row
+  static_assert(KH % kWBWide == 0 && KH % 16 == 0 && kLines <= 4, "whole operand blocks and lines");
   long long dummy = 0;
   (void)dummy;
   constexpr int off = H * KH;  // first state of this wave
@@ -117,14 +119,22 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
   const cfloat_p gmw = ghostMask + off;
   // ---- descending pass: vec[k] = beta[k]*e[k] (kept in b), T[k] = Ush[k]*vec[k], BU[k] = T[k+1] + RR[k]*BU[k+1]
   // wave 1 runs it in phase 0 (BU above the last state is 0), wave 0 in phase 1 from wave 1's (T, BU) of state KH
-  auto descending = [&](const float tIn, const float buIn, const bool accumulate) {
+  auto descending = [&](auto blockStates, const float tIn, const float buIn, const bool accumulate) {
+    constexpr int BS = decltype(blockStates)::value; // states per operand block of this pass
+    constexpr int NB = KH / BS;
+    typedef typename SV<BS>::T SVec;
     // accumulate = false: w[k] = BU[k];  true: w[k] = w[k] + BU[k] (w holds BL + D*vec already)
     SVec u, rr, nu, nrr;
-    EmisBlk<kWB> em, nem;
-    u = LD<kWB, false>::loadAt(rsw, kRowUsh * KP + (NB - 1) * kWB);
-    rr = LD<kWB, false>::loadAt(rsw, kRowRR * KP + (NB - 1) * kWB);
+    EmisBlk<BS> em, nem;
+    u = LD<BS, false>::loadAt(rsw, kRowUsh * KP + (NB - 1) * BS);
+    rr = LD<BS, false>::loadAt(rsw, kRowRR * KP + (NB - 1) * BS);
+    // scalar-cache warm-up (fsmc_kernels.h, touchLines): one dword of every other 64-byte line of this wave's part of the
+    // two rows, so that the pass's first wait covers all the misses at once and the later blocks hit
+    Touched tu, trr;
+    touchRow<0, kLines - 1>(tu, rsw, kRowUsh * KP);
+    touchRow<0, kLines - 1>(trr, rsw, kRowRR * KP);
     if (!accumulate) {
-      em = readEmis<kWB>(e, NB - 1);
+      em = readEmis<BS>(e, NB - 1);
     }
     float tAbove = tIn;  // T of the state above the current one
     float buAbove = buIn; // BU of the state above the current one
@@ -133,6 +143,8 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
       FSMC_WAIT_OPERANDS(dummy);
       if (blk == NB - 1) {
         landed(u, rr);
+        heldRow<kLines - 1>(tu);
+        heldRow<kLines - 1>(trr);
       } else {
         landed(nu, nrr);
         u = nu;
@@ -142,17 +154,17 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         }
       }
       if (blk > 0) {
-        nu = LD<kWB, false>::loadAt(rsw, kRowUsh * KP + (blk - 1) * kWB);
-        nrr = LD<kWB, false>::loadAt(rsw, kRowRR * KP + (blk - 1) * kWB);
+        nu = LD<BS, false>::loadAt(rsw, kRowUsh * KP + (blk - 1) * BS);
+        nrr = LD<BS, false>::loadAt(rsw, kRowRR * KP + (blk - 1) * BS);
         if (!accumulate) {
-          nem = readEmis<kWB>(e, blk - 1);
+          nem = readEmis<BS>(e, blk - 1);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      float T[kWB];
+      float T[BS];
 #pragma unroll
-      for (int i = 0; i < kWB; i += 2) {
-        const int k = blk * kWB + i;
+      for (int i = 0; i < BS; i += 2) {
+        const int k = blk * BS + i;
         f32x2 v = {b[k], b[k + 1]};
         if (!accumulate) {
           v = pmul(v, em.pair(i)); // (in phase 1 wave 0's b already holds vec: the ascending pass made it)
@@ -164,9 +176,9 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         T[i + 1] = t.y;
       }
 #pragma unroll
-      for (int i = kWB - 1; i >= 0; --i) {
-        const int k = blk * kWB + i;
-        const float tNext = (i == kWB - 1) ? tAbove : T[i + 1];
+      for (int i = BS - 1; i >= 0; --i) {
+        const int k = blk * BS + i;
+        const float tNext = (i == BS - 1) ? tAbove : T[i + 1];
         const float bu = tNext + rr[i] * buAbove;
         buAbove = bu;
         w[k] = accumulate ? w[k] + bu : bu;
@@ -180,16 +192,22 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
   };
   // ---- ascending pass: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  x[k] = BL[k] + D[k]*vec[k]
   // wave 0 runs it in phase 0 (BL[0] = 0; it also forms vec), wave 1 in phase 1 from wave 0's BL of state KH
-  auto ascending = [&](const float blIn, const bool first) {
+  auto ascending = [&](auto blockStates, const float blIn, const bool first) {
+    constexpr int BS = decltype(blockStates)::value;
+    constexpr int NB = KH / BS;
+    typedef typename SV<BS>::T SVec;
     // first = true (wave 0): b = beta on entry, vec on exit; w[k] = x[k].  false (wave 1): w[k] = (x[k] + BU[k]) * mask
     SVec d, bt, mk, nd, nbt, nmk;
-    EmisBlk<kWB> em, nem;
-    d = LD<kWB, false>::loadAt(rsw, kRowD * KP);
-    bt = LD<kWB, false>::loadAt(rsw, kRowB * KP);
+    EmisBlk<BS> em, nem;
+    d = LD<BS, false>::loadAt(rsw, kRowD * KP);
+    bt = LD<BS, false>::loadAt(rsw, kRowB * KP);
+    Touched td, tbt;
+    touchRow<1, kLines - 1>(td, rsw, kRowD * KP);
+    touchRow<1, kLines - 1>(tbt, rsw, kRowB * KP);
     if (first) {
-      em = readEmis<kWB>(e, 0);
+      em = readEmis<BS>(e, 0);
     } else {
-      mk = LD<kWB, false>::loadAt(gmw, 0);
+      mk = LD<BS, false>::loadAt(gmw, 0);
     }
     float BL = blIn;
 #pragma unroll
@@ -207,25 +225,27 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         }
       } else {
         landed(d, bt);
+        heldRow<kLines - 1>(td);
+        heldRow<kLines - 1>(tbt);
         if (!first) {
           landed(mk);
         }
       }
       if (blk + 1 < NB) {
-        nd = LD<kWB, false>::loadAt(rsw, kRowD * KP + (blk + 1) * kWB);
-        nbt = LD<kWB, false>::loadAt(rsw, kRowB * KP + (blk + 1) * kWB);
+        nd = LD<BS, false>::loadAt(rsw, kRowD * KP + (blk + 1) * BS);
+        nbt = LD<BS, false>::loadAt(rsw, kRowB * KP + (blk + 1) * BS);
         if (first) {
-          nem = readEmis<kWB>(e, blk + 1);
+          nem = readEmis<BS>(e, blk + 1);
         } else {
-          nmk = LD<kWB, false>::loadAt(gmw, (blk + 1) * kWB);
+          nmk = LD<BS, false>::loadAt(gmw, (blk + 1) * BS);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       // upper half: beta' of a ghost state is BL, not 0 -- every block is multiplied by its part of the 1/0 mask row
       // (x * 1.0f is exact; ghosts only occur in the upper half)
 #pragma unroll
-      for (int i = 0; i < kWB; i += 2) {
-        const int k = blk * kWB + i;
+      for (int i = 0; i < BS; i += 2) {
+        const int k = blk * BS + i;
         f32x2 v = {b[k], b[k + 1]};
         if (first) {
           v = pmul(v, em.pair(i));
@@ -257,18 +277,18 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
     if (H == ph) { // the ascending pass reaches this wave
       const float blIn = ph == 0 ? 0.f : cx.mail[(kW2RowBL + ph - 1) * kWave + cx.lane];
       if ((H >= kW2NW / 2)) {
-        ascending(blIn, false);
+        ascending(std::integral_constant<int, kWB>{}, blIn, false); // three operand rows: the smaller blocks
       } else {
-        ascending(blIn, true);
+        ascending(std::integral_constant<int, kWBWide>{}, blIn, true);
       }
     }
     if (H == kW2NW - 1 - ph) { // the descending pass reaches this wave
       const float tIn = ph == 0 ? 0.f : cx.mail[(kW2RowT + H) * kWave + cx.lane];
       const float buIn = ph == 0 ? 0.f : cx.mail[(kW2RowBU + H) * kWave + cx.lane];
       if ((H >= kW2NW / 2)) {
-        descending(tIn, buIn, false);
+        descending(std::integral_constant<int, kWBWide>{}, tIn, buIn, false);
       } else {
-        descending(tIn, buIn, true);
+        descending(std::integral_constant<int, kWBWide>{}, tIn, buIn, true);
       }
     }
     w2PhaseBarrier();
@@ -284,7 +304,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 {
   constexpr int KP = kW2NW * KH;
   constexpr int NBF = KH / kWBF;
-  static_assert(KH % kWBF == 0, "whole operand blocks");
+  constexpr int kLines = KH / 16;
+  static_assert(KH % kWBF == 0 && KH % 16 == 0 && kLines <= 4, "whole operand blocks and lines");
   typedef typename SV<kWBF>::T SVec;
   long long dummy = 0;
   (void)dummy;
@@ -300,8 +321,12 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     d = LD<kWBF, false>::loadAt(rsw, kRowD * KP);
     u = LD<kWBF, false>::loadAt(rsw, kRowU * KP);
     c4 = LD<kWBF, false>::loadAt(crw, 0);
+    Touched td, tu, tb;
+    touchRow<1, kLines - 1>(td, rsw, kRowD * KP);
+    touchRow<1, kLines - 1>(tu, rsw, kRowU * KP);
     if (complete) {
       bt = LD<kWBF, false>::loadAt(rsw, kRowB * KP);
+      touchRow<1, kLines - 1>(tb, rsw, kRowB * KP);
       em = readEmis<kWBF>(e, 0);
     }
     float AU = auIn;
@@ -323,10 +348,13 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
       } else {
         if (complete) {
           landed(d, u, c4, bt);
+          heldRow<kLines - 1>(tb);
         } else {
           landed(d, u);
           landed(c4);
         }
+        heldRow<kLines - 1>(td);
+        heldRow<kLines - 1>(tu);
       }
       if (blk + 1 < NBF) {
         nd = LD<kWBF, false>::loadAt(rsw, kRowD * KP + (blk + 1) * kWBF);
@@ -380,6 +408,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     SVec bt, nbt;
     EmisBlk<kWBF> em, nem;
     bt = LD<kWBF, false>::loadAt(rsw, kRowB * KP + (NBF - 1) * kWBF);
+    Touched tb;
+    touchRow<0, kLines - 1>(tb, rsw, kRowB * KP);
     em = readEmis<kWBF>(e, NBF - 1);
     float c = cIn; // alphaC of the state above the current one
 #pragma unroll
@@ -387,6 +417,7 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
       FSMC_WAIT_OPERANDS(dummy);
       if (blk == NBF - 1) {
         landed(bt);
+        heldRow<kLines - 1>(tb);
       } else {
         landed(nbt);
         bt = nbt;
@@ -889,7 +920,18 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
               if (h == 0) {
                 cx.mail[row * kWave + lane] = __int_as_float(level | (opening ? 8 : 0) | (closing ? 16 : 0));
               } else {
-                waitVm0(); // this wave's sums of the sites before are in memory before wave 0 may read them
+                // this wave's sums of the sites before are in memory before wave 0 may read them -- but not the requests
+                // for the next site's beta row and emission values issued a moment ago, behind those stores (vector
+                // memory operations retire in order: "at most that many outstanding" means the stores are done)
+                constexpr unsigned nB = (unsigned)K4H, nBE = (unsigned)(K4H + NLE);
+                static_assert(nBE < 64, "vmcnt is a 6-bit counter");
+                if (pos + 2 < hi) {
+                  __builtin_amdgcn_s_waitcnt(0x0F70 | (nBE & 15u) | ((nBE >> 4) << 14));
+                } else if (pos + 1 < hi) {
+                  __builtin_amdgcn_s_waitcnt(0x0F70 | (nB & 15u) | ((nB >> 4) << 14));
+                } else {
+                  waitVm0();
+                }
               }
               w2Barrier();
               if (h != 0) {
