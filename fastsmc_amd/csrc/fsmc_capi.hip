@@ -242,6 +242,12 @@ int familyMember(const fsmc_model* m)
 
 template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half, bool dual = false)
 {
+  if constexpr (KT > 0 && halfBuilt(KT)) {
+    if (dual && half && mode == kModeIbd && !seq) {
+      return track ? decode_kernel<KT, kModeIbd, true, false, true, true>
+                   : decode_kernel<KT, kModeIbd, false, false, true, true>;
+    }
+  }
   if constexpr (KT > 0) {
     if (dual && mode == kModeIbd && !seq) {
       return track ? decode_kernel<KT, kModeIbd, true, false, false, true>
@@ -339,7 +345,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
     m->ctx->lastMember = -(m->KP / 4);
     return m->KP == 192 ? pickQuarterKernel<48>(mode, track) : pickQuarterKernel<64>(mode, track);
   }
-  const bool half = !dual && halfAvailable(mode, m) && m->ctx->betaStride != 1;
+  const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1; // (also with two half-groups per wave)
   if (mode == kModeIbd) {
     m->ctx->lastStride = half ? 2 : 1;
   }
@@ -379,7 +385,7 @@ struct LaunchPlan {
 
 // Decide chunking of the beta stream and the number of resident waves.
 // `items`: the list the waves will pull from when it is not the uploaded group list.  `paired`: two half-groups per
-// wave, `items` holding the union of each pair's windows; such launches store every beta row (stride 1).
+// wave, `items` holding the union of each pair's windows.
 // `share`: the launch runs beside another one and may take 1/share of the workspace limit, in `ws`.
 int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan,
                const std::vector<fsmc_group>* items = nullptr, bool paired = false, unsigned share = 1,
@@ -418,7 +424,8 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / share;
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
-  const bool half = !paired && halfAvailable(mode, m) && ctx->betaStride != 1;
+  const bool half = halfAvailable(mode, m) && ctx->betaStride != 1;
+  (void)paired;
   auto chunkRows = [&](size_t c) { return half ? (c + 1) / 2 : c; };
   const size_t rowsAvail = (size_t)(limit / (vecBytes * slots)); // rows one resident wave may hold
   size_t C, maxChunks;
@@ -1085,8 +1092,9 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   const bool track = (flags & (FSMC_WANT_MEAN | FSMC_WANT_MAP)) != 0;
-  // The queues.  Two half-groups per wave for the half-full groups that pair up within the single-chunk layout at
-  // beta stride 1 (decode_kernel<..., DUAL>); the other groups one per wave, in a kernel that runs beside it.
+  // The queues.  Two half-groups per wave for the half-full groups that pair up within the single-chunk layout
+  // (decode_kernel<..., DUAL>, with beta stride 2 where that is built); the other groups one per wave, in a kernel that
+  // runs beside it.
   KernelFn fnDual = nullptr;
   uint64_t maxLen = 0;
   if (ctx->pairing != 0 && !m->sequence && familyMember(m) > 0) {
@@ -1097,7 +1105,8 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     const size_t vecBytes = (size_t)(familyMember(m) + 3) / 4 * kWave * sizeof(float4);
     const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / 2;
     const size_t rowsAvail = (size_t)(limit / (vecBytes * slots));
-    maxLen = rowsAvail > 16 ? std::min<size_t>(rowsAvail - 6, 1u << 30) : 0;
+    const bool halfDual = halfAvailable(kModeIbd, m) && ctx->betaStride != 1; // a stored row serves two sites
+    maxLen = rowsAvail > 16 ? std::min<size_t>((rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
   }
   fsmc_ctx::IbdQueues& q = ctx->q;
   if (!q.valid || q.serial != ctx->worklistSerial || q.maxLen != maxLen || q.pairing != ctx->pairing) {

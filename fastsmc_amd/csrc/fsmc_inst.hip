@@ -14,6 +14,7 @@ FSMC_DEFINE_KT_DUAL(FSMC_INSTANCE_KT)
     FSMC_INSTANCE_KT == 69 || FSMC_INSTANCE_KT == 96 || FSMC_INSTANCE_KT == 112 || FSMC_INSTANCE_KT == 128
 static_assert(halfBuilt(FSMC_INSTANCE_KT), "keep halfBuilt() and this list in step");
 FSMC_KT_HALF_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
+FSMC_DEFINE_KT_DUAL_HALF(FSMC_INSTANCE_KT)
 #else
 static_assert(!halfBuilt(FSMC_INSTANCE_KT), "keep halfBuilt() and this list in step");
 #endif

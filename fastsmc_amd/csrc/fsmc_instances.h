@@ -57,6 +57,13 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_DEFINE_KT_DUAL(KT)                                                                                        \
   template __global__ void decode_kernel<KT, kModeIbd, true, false, false, true>(const KParams);                     \
   template __global__ void decode_kernel<KT, kModeIbd, false, false, false, true>(const KParams);
+// ... with beta stride 2 (the members beta stride 2 is built for)
+#define FSMC_DECLARE_KT_DUAL_HALF(KT)                                                                                  \
+  extern template __global__ void decode_kernel<KT, kModeIbd, true, false, true, true>(const KParams);               \
+  extern template __global__ void decode_kernel<KT, kModeIbd, false, false, true, true>(const KParams);
+#define FSMC_DEFINE_KT_DUAL_HALF(KT)                                                                                   \
+  template __global__ void decode_kernel<KT, kModeIbd, true, false, true, true>(const KParams);                      \
+  template __global__ void decode_kernel<KT, kModeIbd, false, false, true, true>(const KParams);
 // four waves per group, lane = pair (fsmc_kernels_w2.h): 128 < K <= 256, KH = 48, 64 states per wave
 #define FSMC_W2_KERNELS(X, KH)                                                                                         \
   X(KH, kModeIbd, true)                                                                                                \
@@ -84,6 +91,14 @@ FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 69)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 96)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 112)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 128)
+FSMC_DECLARE_KT_DUAL_HALF(16)
+FSMC_DECLARE_KT_DUAL_HALF(32)
+FSMC_DECLARE_KT_DUAL_HALF(48)
+FSMC_DECLARE_KT_DUAL_HALF(64)
+FSMC_DECLARE_KT_DUAL_HALF(69)
+FSMC_DECLARE_KT_DUAL_HALF(96)
+FSMC_DECLARE_KT_DUAL_HALF(112)
+FSMC_DECLARE_KT_DUAL_HALF(128)
 FSMC_DECLARE_KT_DUAL(16)
 FSMC_DECLARE_KT_DUAL(32)
 FSMC_DECLARE_KT_DUAL(48)

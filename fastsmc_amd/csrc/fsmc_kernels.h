@@ -1184,13 +1184,14 @@ constexpr int minWavesPerSimd(const int KT)
 // 32..63 half B, each over ITS OWN decode and scan window; the wave walks the union of the two windows and a lane is
 // (re)initialised where its own window opens -- beta at site to-1 of its window, alpha at site from -- so within its
 // window every value is produced by exactly the operations of a stand-alone decode (what a lane computes outside its
-// window is overwritten before it is used and never reaches an output).  Single-chunk layout, beta stride 1; the
-// work list is an array of item = {group A, group B} (B may be empty) prepared by the host library.
+// window is overwritten before it is used and never reaches an output).  Single-chunk layout, beta stride 1 or 2 (with
+// stride 2 a window may end at a site whose row is recomputed in the alpha sweep: the re-initialisation is repeated
+// there); the work list is an array of item = {group A, group B} (B may be empty) prepared by the host library.
 template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF, bool DUAL = false>
 __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(const KParams p)
 {
   static_assert(!HALF || (!SEQ && MODE == kModeIbd), "beta stride 2 is built for the array-mode IBD decode");
-  static_assert(!DUAL || (MODE == kModeIbd && !SEQ && !HALF && KT > 0), "two half-groups per wave: array-mode IBD, stride 1");
+  static_assert(!DUAL || (MODE == kModeIbd && !SEQ && KT > 0), "two half-groups per wave: array-mode IBD");
   // array mode with a compile-time K: the backward loops are rotated (operand-free step tails overlap the next
   // step's first operand requests)
   constexpr bool kRotate = KT > 0 && kPacked && !SEQ;
@@ -1778,6 +1779,24 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             FSMC_END(cycW, 9);
             const float bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, eq, tabs.ghostMask, cycW);
             scale_pk<KT, KA>(b, w, bsum);
+            if constexpr (DUAL) {
+              // the lanes whose own window ends at this site start from beta = 1 here (HMM.cpp:887-897), exactly what
+              // pass B gave them (and did not store: the row of an even offset): 1.0f * (1.0f / sum of K ones)
+              if (__builtin_expect(pos == toA - 1 || pos == toB - 1, 0)) {
+                float ones = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  ones = ones + ((!kGhost<KT> || k < p.K) ? 1.0f : 0.f);
+                }
+                const float c1 = 1.0f / ones;
+                const bool sel = myTo - 1 == pos;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  const float init = ((!kGhost<KT> || k < p.K) ? 1.0f : 0.f) * c1;
+                  b[k] = sel ? init : b[k];
+                }
+              }
+            }
           } else {
             readLanded();
             beta_step<KT, KA>(K, b, w, tabs, rowq, eq, cycW);

@@ -1,7 +1,7 @@
 """Two half-groups per wavefront (decode_kernel<..., DUAL>; fsmc_ctx_set_pairing): hashing-mode batches of at most 32
 pairs share a wave, each lane decoded over its OWN group's decode and scan windows.  The records must be the bytes of
 the unpaired run (and of the oracle): different windows in the two halves, a half that starts later / ends earlier than
-the other, one-site windows, ragged halves, segment ages on and off, several family members.  Groups that do not pair
+the other, one-site windows, ragged halves, segment ages on and off, several family members, both beta strides.  Groups that do not pair
 (more than 32 pairs, or a window too long for the paired kernel's single-chunk layout) run in a second kernel of the
 same decode and land in the same record list."""
 import numpy as np
@@ -50,7 +50,11 @@ def test_paired_half_groups_match_the_unpaired_run_and_the_oracle(small_problem,
               (32, 300, S, 320, S), (9, 330, S, 330, S - 1),           # windows ending at the last site
               (1, 200, 201, 200, 201), (32, 200, 202, 200, 202),       # one- and two-site windows
               (64, 50, 500, 60, 480), (40, 60, 510, 60, 510),          # full groups: second kernel of the same decode
-              (32, 10, 600, 300, 310), (32, 20, 610, 25, 600)]         # a short scan window inside a long decode window
+              (32, 10, 600, 300, 310), (32, 20, 610, 25, 600),         # a short scan window inside a long decode window
+              (32, 50, 301, 60, 290), (32, 60, 331, 60, 331)]          # windows that end at an even offset of the union: with
+                                                                        # beta stride 2 that row is recomputed in the alpha
+                                                                        # sweep, where the lanes of the half that ends there
+                                                                        # must start from beta = 1 again
     wins, first = [], 0
     for cnt, frm, to, sf, st in shapes:
         wins.append((first, cnt, frm, to, sf, st))
@@ -61,9 +65,13 @@ def test_paired_half_groups_match_the_unpaired_run_and_the_oracle(small_problem,
     ctx.upload_haps(small_problem["bits"], S)
     plain, n0 = _run(ctx, model, pairs, wins, flags, pairing=0)
     paired, n1 = _run(ctx, model, pairs, wins, flags, pairing=1)
+    assert ctx.last_beta_stride() == 2
+    ctx.set_beta_stride(1)
+    paired1, n2 = _run(ctx, model, pairs, wins, flags, pairing=1)
+    assert ctx.last_beta_stride() == 1
     ctx.close()
-    assert n0 == 0 and 0 < n1 < len(wins)  # the second run really put two groups on one wave
-    assert paired.tobytes() == plain.tobytes()
+    assert n0 == 0 and 0 < n1 < len(wins) and n2 > 0  # the paired runs really put two groups on one wave
+    assert paired.tobytes() == plain.tobytes() and paired1.tobytes() == plain.tobytes()
     want = _oracle(pm, folded, pairs, wins, bool(flags & capi.FSMC_WANT_MEAN), bool(flags & capi.FSMC_WANT_MAP))
     assert paired.size == want.size and want.size > 10
     for f_got, f_want in FIELDS:
