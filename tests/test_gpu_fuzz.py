@@ -69,3 +69,57 @@ def test_random_worklists(small_problem, seed):
     assert got.size == want.size
     for f_got, f_want in FIELDS:
         np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f_got)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_hashing_style_worklists_pair_up(small_problem, seed):
+    """Half-full groups with similar windows (what the hashing pre-filter produces): most of them are decoded two to a
+    wave, at either beta stride, beside the ones that find no partner -- every record against the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    pm = small_problem["model"]
+    folded = small_problem["folded"]
+    S = pm.S
+    allp = O.enumerate_all_pairs(32)
+    wins, first = [], 0
+    for _ in range(int(rng.integers(8, 15))):
+        cnt = int(rng.choice([1, 7, 16, 31, 32, 32, 32, 40]))
+        length = int(rng.choice([1, 2, 65, 128, 129, 200, 320]))
+        frm = int(rng.integers(0, max(1, min(40, S - length))))
+        frm += int(rng.choice([0, 0, 100, 250]))
+        frm = min(frm, S - length)
+        to = frm + length
+        sfrm = int(rng.integers(frm, to))
+        sto = int(rng.integers(sfrm + 1, to + 1))
+        wins.append((first, cnt, frm, to, sfrm, sto))
+        first += cnt
+    start = int(rng.integers(0, len(allp) - first))
+    pairs = allp[start:start + first]
+    groups = np.zeros(len(wins), capi.GROUP_DTYPE)
+    for g, w in zip(groups, wins):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    want_mean, want_map = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    flags = (capi.FSMC_WANT_MEAN if want_mean else 0) | (capi.FSMC_WANT_MAP if want_map else 0)
+    ctx = capi.Context(0)
+    ctx.set_beta_stride(int(rng.choice([0, 1, 2])))
+    model = ctx.create_model(pm)
+    ctx.upload_haps(small_problem["bits"], S)
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    got = ctx.decode_ibd(model, pr, groups, flags)
+    n_items = ctx.last_items()
+    ctx.close()
+    assert n_items >= 1  # at least one wave took two groups
+    want = []
+    for first, cnt, frm, to, sfrm, sto in wins:
+        sub = pairs[first:first + cnt]
+        ob = np.stack([(folded[a] ^ folded[b])[frm:to] for a, b in sub])
+        hb = np.stack([(folded[a] & folded[b])[frm:to] for a, b in sub])
+        post, _ = O.decode_batch(pm, ob, hb, frm, to)
+        full = np.zeros((S, pm.K, cnt), np.float32)
+        full[frm:to] = post[frm:to]
+        for v in range(cnt):
+            want.append(O.ibd_scan_pair(pm, full, v, sfrm, sto, want_mean=want_mean, want_map=want_map,
+                                        pair_ordinal=first + v))
+    want = np.concatenate(want) if want else np.zeros(0, O.IBD_DTYPE)
+    assert got.size == want.size
+    for f_got, f_want in FIELDS:
+        np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f_got)
