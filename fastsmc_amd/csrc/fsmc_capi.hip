@@ -298,7 +298,8 @@ bool quarterLanes(int mode, const fsmc_model* m)
 bool waveGroups(int mode, const fsmc_model* m)
 {
   return familyMember(m) == 0 && m->K > 128 && m->K <= 256 && !m->sequence && (m->KP == 192 || m->KP == 256) &&
-         (mode == kModeIbd || mode == kModeDump || mode == kModeSums) && std::getenv("FSMC_WIDE_Q4") == nullptr;
+         (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair) &&
+         std::getenv("FSMC_WIDE_Q4") == nullptr;
 }
 
 template <int KH> KernelFn pickWaveGroupKernel(int mode, bool track)
@@ -308,6 +309,9 @@ template <int KH> KernelFn pickWaveGroupKernel(int mode, bool track)
   }
   if (mode == kModeSums) {
     return decode_kernel_w2<KH, kModeSums, false>;
+  }
+  if (mode == kModePerPair) {
+    return decode_kernel_w2<KH, kModePerPair, false>;
   }
   return decode_kernel_w2<KH, kModeDump, false>;
 }
@@ -1470,7 +1474,7 @@ int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model* m, const float* exp_co
   p.expCoal = (const float*)base;
   p.ppMean = mean ? (float*)(base + coalBytes) : nullptr;
   p.ppMap = map ? (int*)(base + coalBytes + n * sizeof(float)) : nullptr;
-  rc = launch(ctx, fn, p, plan.slots);
+  rc = launch(ctx, fn, p, plan.slots, blockThreads(kModePerPair, m));
   if (rc != FSMC_OK) {
     return rc;
   }

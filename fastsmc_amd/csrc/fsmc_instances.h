@@ -69,7 +69,8 @@ constexpr bool halfBuilt(const int KT)
   X(KH, kModeIbd, true)                                                                                                \
   X(KH, kModeIbd, false)                                                                                               \
   X(KH, kModeDump, false)                                                                                              \
-  X(KH, kModeSums, false)
+  X(KH, kModeSums, false)                                                                                              \
+  X(KH, kModePerPair, false)
 #define FSMC_DECLARE_W2(KH, MODE, TRACK) extern template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
 #define FSMC_DEFINE_W2(KH, MODE, TRACK) template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
 #define FSMC_DECLARE_Q4(KQ, MODE, TRACK) extern template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);

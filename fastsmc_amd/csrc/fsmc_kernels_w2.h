@@ -491,8 +491,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 template <int KH, int MODE, bool TRACK>
 __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KParams p)
 {
-  static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums,
-                "the wave-group kernel has the IBD, the dump and the sums-over-pairs consumer");
+  static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums || MODE == kModePerPair,
+                "the consumers of the wave-group kernel");
   constexpr int KP = kW2NW * KH;
   constexpr int K4H = KH / 4;        // float4 per lane of this wave's part of a K-vector
   constexpr int E4H = 3 * K4H;       // float4 of one site's emission values of this wave's states (three classes)
@@ -501,6 +501,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
   __shared__ float4 betaLds[kW2NW][K4H * kWave];  // [wave]: landing zone of the next site's beta row (its part)
   __shared__ float mailLds[kW2Mail * kWave];
   __shared__ float4 piLds[KP / 4];   // initialStateProb, zero padded
+  __shared__ float4 coalLds[MODE == kModePerPair ? KP / 4 : 1]; // kModePerPair: expected coalescence times, zero padded
   __shared__ unsigned groupLds;
   __shared__ unsigned char clsLds[kW2NW][kWave]; // kModeSums: observation class of every pair at the current site
 
@@ -522,6 +523,9 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
   const cfloat_p rowSets = (cfloat_p)p.rowSets;
   if (threadIdx.x < (unsigned)(KP / 4)) {
     piLds[threadIdx.x] = reinterpret_cast<const float4*>(p.pi)[threadIdx.x];
+    if (MODE == kModePerPair) {
+      coalLds[threadIdx.x] = reinterpret_cast<const float4*>(p.expCoal)[threadIdx.x];
+    }
   }
   w2Barrier();
   const cfloat_p tCR = (cfloat_p)p.cR;
@@ -853,6 +857,49 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
           __builtin_amdgcn_wave_barrier();
           if (pos + 1 < hi) {
             fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
+          }
+        }
+
+        if (MODE == kModePerPair) {
+          // HMM::writePerPairOutput (HMM.cpp:1378-1409): mean = sum_k post*E[t_k] (k ascending from 0.f), MAP = first
+          // strictly larger posterior -- both walk the states in order, hence the waves in order (three hand-overs)
+          float mean = 0.f, best = 0.f;
+          int arg = 0;
+#pragma unroll
+          for (int ph = 0; ph < kW2NW; ++ph) {
+            if (h == ph) {
+              if (ph > 0) {
+                mean = cx.mail[(kW2RowScan + ph - 1) * kWave + lane];
+                best = cx.mail[(kW2RowStep + ph - 1) * kWave + lane];
+                arg = __float_as_int(cx.mail[(kW2RowComb + ph - 1) * kWave + lane]);
+              }
+#pragma unroll
+              for (int k4 = 0; k4 < K4H; ++k4) {
+                const float4 tc = coalLds[h * K4H + k4];
+                const float t4[4] = {tc.x, tc.y, tc.z, tc.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float post = w[4 * k4 + i] * cq;
+                  mean = mean + post * t4[i];
+                  if (best < post) {
+                    arg = h * KH + 4 * k4 + i;
+                    best = post;
+                  }
+                }
+              }
+              if (ph < kW2NW - 1) {
+                cx.mail[(kW2RowScan + ph) * kWave + lane] = mean;
+                cx.mail[(kW2RowStep + ph) * kWave + lane] = best;
+                cx.mail[(kW2RowComb + ph) * kWave + lane] = __int_as_float(arg);
+              }
+            }
+            if (ph < kW2NW - 1) {
+              w2Barrier();
+            }
+          }
+          if (h == kW2NW - 1 && valid) {
+            if (p.ppMean) p.ppMean[(size_t)pairIdx * p.S + pos] = mean;
+            if (p.ppMap) p.ppMap[(size_t)pairIdx * p.S + pos] = arg;
           }
         }
 

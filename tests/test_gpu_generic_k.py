@@ -27,14 +27,14 @@ def _problem(K, n_hap=64, S=200, seed=11):
 
 def _member(K, consumer="ibd"):
     """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; beyond, the four-waves-per-group
-    kernel (1000 + states per wave) for the IBD and dump consumers and the four-lanes-per-pair kernel (-states per lane)
-    for the per-pair consumer -- or for all three with FSMC_WIDE_Q4 in the environment."""
+    kernel (1000 + states per wave), or the four-lanes-per-pair kernel (-states per lane) with FSMC_WIDE_Q4 in the
+    environment."""
     if K == 69:
         return 69
     if K <= 128:
         return (K + 15) // 16 * 16
     kq = 48 if K <= 192 else 64
-    return -kq if consumer == "per_pair" or os.environ.get("FSMC_WIDE_Q4") else 1000 + kq
+    return -kq if os.environ.get("FSMC_WIDE_Q4") else 1000 + kq
 
 
 def _stride(K):
