@@ -297,23 +297,27 @@ bool quarterLanes(int mode, const fsmc_model* m)
 // of the same models.  FSMC_WIDE_Q4 in the environment keeps the four-lanes-per-pair kernel (A/B measurements, tests).
 bool waveGroups(int mode, const fsmc_model* m)
 {
-  return familyMember(m) == 0 && m->K > 128 && m->K <= 256 && !m->sequence && (m->KP == 192 || m->KP == 256) &&
+  return familyMember(m) == 0 && m->K > 128 && m->K <= 256 && (m->KP == 192 || m->KP == 256) &&
          (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair) &&
-         std::getenv("FSMC_WIDE_Q4") == nullptr;
+         (m->sequence || std::getenv("FSMC_WIDE_Q4") == nullptr);
 }
 
-template <int KH> KernelFn pickWaveGroupKernel(int mode, bool track)
+template <int KH, bool SEQ> KernelFn pickWaveGroupKernelOf(int mode, bool track)
 {
   if (mode == kModeIbd) {
-    return track ? decode_kernel_w2<KH, kModeIbd, true> : decode_kernel_w2<KH, kModeIbd, false>;
+    return track ? decode_kernel_w2<KH, kModeIbd, true, SEQ> : decode_kernel_w2<KH, kModeIbd, false, SEQ>;
   }
   if (mode == kModeSums) {
-    return decode_kernel_w2<KH, kModeSums, false>;
+    return decode_kernel_w2<KH, kModeSums, false, SEQ>;
   }
   if (mode == kModePerPair) {
-    return decode_kernel_w2<KH, kModePerPair, false>;
+    return decode_kernel_w2<KH, kModePerPair, false, SEQ>;
   }
-  return decode_kernel_w2<KH, kModeDump, false>;
+  return decode_kernel_w2<KH, kModeDump, false, SEQ>;
+}
+template <int KH> KernelFn pickWaveGroupKernel(int mode, bool track, bool seq)
+{
+  return seq ? pickWaveGroupKernelOf<KH, true>(mode, track) : pickWaveGroupKernelOf<KH, false>(mode, track);
 }
 
 // threads of a workgroup of the kernel pickKernel returns for this mode and model
@@ -340,7 +344,8 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
       m->ctx->lastStride = 1;
     }
     m->ctx->lastMember = 1000 + m->KP / kW2NW; // 1048 / 1064: four waves per group, 48 / 64 states per wave
-    return m->KP == 192 ? pickWaveGroupKernel<48>(mode, track) : pickWaveGroupKernel<64>(mode, track);
+    return m->KP == 192 ? pickWaveGroupKernel<48>(mode, track, m->sequence != 0)
+                        : pickWaveGroupKernel<64>(mode, track, m->sequence != 0);
   }
   if (quarterLanes(mode, m)) {
     if (mode == kModeIbd) {

@@ -66,13 +66,19 @@ constexpr bool halfBuilt(const int KT)
   template __global__ void decode_kernel<KT, kModeIbd, false, false, true, true>(const KParams);
 // four waves per group, lane = pair (fsmc_kernels_w2.h): 128 < K <= 256, KH = 48, 64 states per wave
 #define FSMC_W2_KERNELS(X, KH)                                                                                         \
-  X(KH, kModeIbd, true)                                                                                                \
-  X(KH, kModeIbd, false)                                                                                               \
-  X(KH, kModeDump, false)                                                                                              \
-  X(KH, kModeSums, false)                                                                                              \
-  X(KH, kModePerPair, false)
-#define FSMC_DECLARE_W2(KH, MODE, TRACK) extern template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
-#define FSMC_DEFINE_W2(KH, MODE, TRACK) template __global__ void decode_kernel_w2<KH, MODE, TRACK>(const KParams);
+  X(KH, kModeIbd, true, false)                                                                                         \
+  X(KH, kModeIbd, false, false)                                                                                        \
+  X(KH, kModeDump, false, false)                                                                                       \
+  X(KH, kModeSums, false, false)                                                                                       \
+  X(KH, kModePerPair, false, false)                                                                                    \
+  X(KH, kModeIbd, true, true)                                                                                          \
+  X(KH, kModeIbd, false, true)                                                                                         \
+  X(KH, kModeDump, false, true)                                                                                        \
+  X(KH, kModeSums, false, true)                                                                                        \
+  X(KH, kModePerPair, false, true)
+#define FSMC_DECLARE_W2(KH, MODE, TRACK, SEQ)                                                                          \
+  extern template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ>(const KParams);
+#define FSMC_DEFINE_W2(KH, MODE, TRACK, SEQ) template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ>(const KParams);
 #define FSMC_DECLARE_Q4(KQ, MODE, TRACK) extern template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 #define FSMC_DEFINE_Q4(KQ, MODE, TRACK) template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 

@@ -30,8 +30,10 @@ namespace fsmc
 constexpr int kW2NW = 4;    // waves per group
 // mailbox rows (64 floats each): carries of the recurrences per boundary, partial sums per wave
 constexpr int kW2RowT = 0, kW2RowBU = 3, kW2RowBL = 6, kW2RowC = 0, kW2RowAU = 3; // (+ boundary 0..2)
-constexpr int kW2RowStep = 9, kW2RowComb = 13, kW2RowScan = 17, kW2RowLevel = 21;
-constexpr int kW2Mail = 23;
+constexpr int kW2RowStep = 9, kW2RowComb = 13, kW2RowLevel = 17;
+constexpr int kW2RowScan = kW2RowStep; // (the scan's partial sums follow the combine: the step's rows are free then)
+constexpr int kW2RowMean = kW2RowT;    // (kModePerPair: likewise the carries' rows)
+constexpr int kW2Mail = 19;
 constexpr int kWBF = 8;    // ... and of the forward pass (four tables at a time)
 constexpr int kWBWide = 8;  // ... of the passes with two operand rows (16-state blocks measured 4 % slower at 64 states per wave: spills)
 constexpr int kWB = 8;     // states per operand block of the backward passes here (two waves' roles in one kernel leave
@@ -105,7 +107,7 @@ template <int KH> __device__ __forceinline__ void w2Scale(float (&v)[KH], const 
 
 // One backward step (HMM.cpp:957-1016).  b: this wave's half of beta of site pos+1 on entry, of site pos on exit.
 // rs: the step's RowSet (all 2*KH states); e: this lane's emission values of THIS WAVE's states (LDS).
-template <int KH, int H>
+template <int KH, int H, bool SCALE = true>
 __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], float (&w)[KH], cfloat_p rs,
                                              const float4* e, cfloat_p ghostMask)
 {
@@ -293,12 +295,19 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
     }
     w2PhaseBarrier();
   }
-  const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
-  w2Scale<KH>(b, w, total);
+  if constexpr (SCALE) {
+    const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
+    w2Scale<KH>(b, w, total);
+  } else { // the un-normalised half-step of sequence mode (HMM.cpp:915-922)
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      b[k] = w[k];
+    }
+  }
 }
 
 // One forward step (HMM.cpp:799-830) + scaling.  a: this wave's half of alpha of site pos-1 on entry, of pos on exit.
-template <int KH, int H>
+template <int KH, int H, bool SCALE = true>
 __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], float (&w)[KH], cfloat_p rs, cfloat_p cR,
                                               const float4* e)
 {
@@ -471,8 +480,15 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     }
     w2PhaseBarrier();
   }
-  const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
-  w2Scale<KH>(a, w, total);
+  if constexpr (SCALE) {
+    const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
+    w2Scale<KH>(a, w, total);
+  } else { // the un-normalised half-step of sequence mode (HMM.cpp:760-767)
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      a[k] = w[k];
+    }
+  }
 }
 
 // The wave's role is a compile-time parameter of the step functions (its phases are then straight-line code); the
@@ -488,14 +504,16 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
   } while (0)
 
 // Work item = one group of <= 64 pairs; workgroup = kW2NW waves; two workgroups per CU (the landing zones fill LDS).
-template <int KH, int MODE, bool TRACK>
+// SEQ: sequence mode (two steps per site, a fourth emission row per site: fsmc_kernels.h) -- the same schedule as there.
+template <int KH, int MODE, bool TRACK, bool SEQ = false>
 __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KParams p)
 {
   static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums || MODE == kModePerPair,
                 "the consumers of the wave-group kernel");
   constexpr int KP = kW2NW * KH;
   constexpr int K4H = KH / 4;        // float4 per lane of this wave's part of a K-vector
-  constexpr int E4H = 3 * K4H;       // float4 of one site's emission values of this wave's states (three classes)
+  constexpr int NC = SEQ ? 4 : 3;    // emission rows per site: three observation classes (+ the gap's homozygous row)
+  constexpr int E4H = NC * K4H;      // float4 of one site's emission values of this wave's states
   constexpr int NLE = (E4H + kWave - 1) / kWave;
   __shared__ float4 emisLds[kW2NW][2][E4H];       // [wave][ring slot][class * K4H + k4]
   __shared__ float4 betaLds[kW2NW][K4H * kWave];  // [wave]: landing zone of the next site's beta row (its part)
@@ -582,13 +600,14 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
       return x ? 0 : 1 + t;
     };
     // this wave's states of the three emission rows of site q into its ring slot (q & 1), by LDS-DMA
-    auto stageEmis = [&](const int q) {
+    auto stageEmis = [&](const int qIn) {
+      const int q = __builtin_amdgcn_readfirstlane(qIn); // (wave-uniform by construction: the ring slot is an M0 value)
 #pragma unroll
       for (int i = 0; i < NLE; ++i) {
         const int idx = lane + i * kWave; // class * K4H + k4
         if (idx < E4H) {
           const int cls = idx / K4H, k4 = idx - cls * K4H;
-          const float4* src = p.emis3 + (size_t)q * (3 * (KP / 4)) + (size_t)cls * (KP / 4) + h * K4H + k4;
+          const float4* src = p.emis3 + (size_t)q * (NC * (KP / 4)) + (size_t)cls * (KP / 4) + h * K4H + k4;
           dmaToLds((gf32x4_p)src, &emisLds[h][q & 1][i * kWave]);
         }
       }
@@ -655,9 +674,32 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
     };
     auto betaStepInto = [&](float (&b)[KH], float (&w)[KH], const int q) { // beta of site q -> beta of site q-1
       const int c = obsClass(q);
-      const cfloat_p rsq = rowSetOfRow(stepRowOf(q));
+      const cfloat_p rsq = rowSetOfRow(SEQ ? __builtin_amdgcn_readfirstlane(p.rowSiteB[q]) : stepRowOf(q));
       const float4* eq = &emisLds[h][q & 1][c * K4H];
       FSMC_W2_ROLE(h, (beta_step_w2<KH, H>(cx, b, w, rsq, eq, ghostMask)));
+    };
+    // sequence mode: the un-normalised half-step across the gap (q-1, q), with the homozygous emission row of site q
+    // (the fourth row of its ring slot)
+    auto betaGapStep = [&](float (&b)[KH], float (&w)[KH], const int q) {
+      const cfloat_p rsq = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapB[q]));
+      const float4* eq = &emisLds[h][q & 1][3 * K4H];
+      FSMC_W2_ROLE(h, (beta_step_w2<KH, H, false>(cx, b, w, rsq, eq, ghostMask)));
+    };
+    // the site step out of q = pos+1 (its rows are in the ring), then the half-step towards pos-1 unless pos is the
+    // window start; the vector carried from site to site is the STORED one (after the half-step)
+    auto betaSeqStep = [&](float (&b)[KH], float (&w)[KH], const int pos) {
+      const int q = pos + 1;
+      waitVm0(); // the rows of site q have landed
+      __builtin_amdgcn_wave_barrier();
+      if (pos > from) {
+        stageEmis(pos); // into the slot of site pos + 2, whose steps are over
+      }
+      betaStepInto(b, w, q);
+      if (pos > from) {
+        waitVm0();
+        __builtin_amdgcn_wave_barrier();
+        betaGapStep(b, w, pos);
+      }
     };
 
     float w[KH];
@@ -681,20 +723,34 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
         }
         return false;
       };
-      bool stored = afterBeta(to - 1);
-      if (to - 2 >= from) {
-        stageEmis(to - 1);
-        stored = false; // (the request is behind the stores: wait for everything once)
-      }
-      for (int pos = to - 2; pos >= from; --pos) {
-        const int q = pos + 1;
-        waitEmisRows(stored);
-        __builtin_amdgcn_wave_barrier();
-        if (pos - 1 >= from) {
-          stageEmis(q - 1);
+      if constexpr (SEQ) {
+        if (to - 1 > from) {
+          stageEmis(to - 1);
+          waitVm0();
+          __builtin_amdgcn_wave_barrier();
+          betaGapStep(b, w, to - 1);
         }
-        betaStepInto(b, w, q);
-        stored = afterBeta(pos);
+        afterBeta(to - 1);
+        for (int pos = to - 2; pos >= from; --pos) {
+          betaSeqStep(b, w, pos);
+          afterBeta(pos);
+        }
+      } else {
+        bool stored = afterBeta(to - 1);
+        if (to - 2 >= from) {
+          stageEmis(to - 1);
+          stored = false; // (the request is behind the stores: wait for everything once)
+        }
+        for (int pos = to - 2; pos >= from; --pos) {
+          const int q = pos + 1;
+          waitEmisRows(stored);
+          __builtin_amdgcn_wave_barrier();
+          if (pos - 1 >= from) {
+            stageEmis(q - 1);
+          }
+          betaStepInto(b, w, q);
+          stored = afterBeta(pos);
+        }
       }
     }
 
@@ -732,24 +788,42 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
         int pos;
         if (hi == to) {
           betaInit(b);
+          if constexpr (SEQ) {
+            if (to - 1 > from) {
+              stageEmis(to - 1);
+              waitVm0();
+              __builtin_amdgcn_wave_barrier();
+              betaGapStep(b, w, to - 1);
+            }
+          }
           storeHalf(chunkbuf + (size_t)(to - 1 - lo) * vecF4, b);
           pos = to - 2;
         } else {
           loadHalf(ckpt + (size_t)(j + 1) * vecF4, b);
           pos = hi - 1;
-        }
-        if (pos >= lo) {
-          stageEmis(pos + 1);
-        }
-        for (; pos >= lo; --pos) {
-          const int q = pos + 1;
-          waitVm0();
-          __builtin_amdgcn_wave_barrier();
-          if (pos - 1 >= lo) {
-            stageEmis(q - 1);
+          if constexpr (SEQ) {
+            stageEmis(hi); // the checkpoint is the stored vector of site hi: its rows next
           }
-          betaStepInto(b, w, q);
-          storeHalf(chunkbuf + (size_t)(pos - lo) * vecF4, b);
+        }
+        if constexpr (SEQ) {
+          for (; pos >= lo; --pos) {
+            betaSeqStep(b, w, pos);
+            storeHalf(chunkbuf + (size_t)(pos - lo) * vecF4, b);
+          }
+        } else {
+          if (pos >= lo) {
+            stageEmis(pos + 1);
+          }
+          for (; pos >= lo; --pos) {
+            const int q = pos + 1;
+            waitVm0();
+            __builtin_amdgcn_wave_barrier();
+            if (pos - 1 >= lo) {
+              stageEmis(q - 1);
+            }
+            betaStepInto(b, w, q);
+            storeHalf(chunkbuf + (size_t)(pos - lo) * vecF4, b);
+          }
         }
         if (j > 0) {
           loadHalf(saveA, a);
@@ -759,8 +833,11 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       waitVm0();
       fetchBeta(chunkbuf);
+      // sites whose emission rows the sweep of this chunk needs: sequence mode also takes the half-step out of the
+      // chunk's last site, with the homozygous row of the site behind it
+      const int stageEnd = SEQ ? (hi + 1 < to ? hi + 1 : to) : hi;
       stageEmis(lo);
-      if (lo + 1 < hi) {
+      if (lo + 1 < stageEnd) {
         stageEmis(lo + 1);
       }
       waitVm0();
@@ -786,6 +863,17 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
           const cfloat_p rsp = rowSetOfRow(stepRowOf(pos));
           FSMC_W2_ROLE(h, (alpha_step_w2<KH, H>(cx, a, w, rsp, tCR, e)));
         }
+        if constexpr (SEQ) {
+          // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step across the gap
+          // to the next site (HMM.cpp:764-767); the last site of the window keeps its alpha
+          if (pos < to - 1) {
+            waitVm0(); // the rows of site pos + 1 (requested a site ago) have landed
+            __builtin_amdgcn_wave_barrier();
+            const cfloat_p rsg = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapF[pos + 1]));
+            const float4* eg = &emisLds[h][(pos + 1) & 1][3 * K4H];
+            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H, false>(cx, a, w, rsg, tCR, eg)));
+          }
+        }
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
         waitVm0();
         __builtin_amdgcn_wave_barrier();
@@ -808,7 +896,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
         if (MODE != kModeSums && pos + 1 < hi) {
           fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
         }
-        if (pos + 2 < hi) {
+        if (pos + 2 < stageEnd) {
           stageEmis(pos + 2);
         }
 
@@ -869,7 +957,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
           for (int ph = 0; ph < kW2NW; ++ph) {
             if (h == ph) {
               if (ph > 0) {
-                mean = cx.mail[(kW2RowScan + ph - 1) * kWave + lane];
+                mean = cx.mail[(kW2RowMean + ph - 1) * kWave + lane];
                 best = cx.mail[(kW2RowStep + ph - 1) * kWave + lane];
                 arg = __float_as_int(cx.mail[(kW2RowComb + ph - 1) * kWave + lane]);
               }
@@ -888,7 +976,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
                 }
               }
               if (ph < kW2NW - 1) {
-                cx.mail[(kW2RowScan + ph) * kWave + lane] = mean;
+                cx.mail[(kW2RowMean + ph) * kWave + lane] = mean;
                 cx.mail[(kW2RowStep + ph) * kWave + lane] = best;
                 cx.mail[(kW2RowComb + ph) * kWave + lane] = __int_as_float(arg);
               }
@@ -972,7 +1060,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
                 // memory operations retire in order: "at most that many outstanding" means the stores are done)
                 constexpr unsigned nB = (unsigned)K4H, nBE = (unsigned)(K4H + NLE);
                 static_assert(nBE < 64, "vmcnt is a 6-bit counter");
-                if (pos + 2 < hi) {
+                if (pos + 2 < stageEnd) {
                   __builtin_amdgcn_s_waitcnt(0x0F70 | (nBE & 15u) | ((nBE >> 4) << 14));
                 } else if (pos + 1 < hi) {
                   __builtin_amdgcn_s_waitcnt(0x0F70 | (nB & 15u) | ((nB >> 4) << 14));

@@ -127,7 +127,7 @@ def test_per_pair_and_sums(gpu, seq_problem):
         np.testing.assert_array_equal(got, w)
 
 
-@pytest.mark.parametrize("K", [12, 100])
+@pytest.mark.parametrize("K", [12, 100, 150, 200, 256])
 def test_generic_k_sequence(K):
     tables = synth.make_model_tables(K)
     haps = synth.make_haps(64, 150, seed=5, cm_per_mb=1.2, bp_per_site=2500, switch_per_cm=2.0)
@@ -143,9 +143,30 @@ def test_generic_k_sequence(K):
     groups = capi.whole_sequence_groups(len(pairs), pm.S)
     _assert_records_equal(ctx.decode_ibd(model, _pairs_array(pairs), groups),
                           O.decode_pairs_ibd(pm, folded, pairs, batch_size=64))
+    if K > 128:  # four waves per group (48 / 64 states a wave), also in sequence mode
+        assert ctx.last_kernel() == 1000 + (48 if K <= 192 else 64)
     ctx.upload_worklist(_pairs_array(pairs), groups)
     post = ctx.decode_posteriors(model)
-    np.testing.assert_array_equal(post[0], _oracle_posterior(sp, pm, pairs[:64], 0, pm.S))
+    wpost = _oracle_posterior(sp, pm, pairs[:64], 0, pm.S)
+    np.testing.assert_array_equal(post[0], wpost)
+    if K > 128:
+        # the other consumers of the wave-group kernel in sequence mode, and the chunked beta stream
+        ctx.upload_worklist(_pairs_array(pairs[:64]), capi.whole_sequence_groups(64, pm.S))
+        mean, mp = ctx.decode_per_pair(model, pm.exp_times)
+        wmean, wmap, _ = O.per_pair_output(pm, wpost, 64)
+        np.testing.assert_array_equal(mean, wmean)
+        np.testing.assert_array_equal(mp, wmap)
+        ob = np.stack([folded[a] ^ folded[b] for a, b in pairs[:64]])
+        hb = np.stack([folded[a] & folded[b] for a, b in pairs[:64]])
+        s_, _ = ctx.decode_sums(model)
+        wsum = np.zeros((pm.S, pm.K), np.float32)
+        O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
+        np.testing.assert_array_equal(s_, wsum)
+        ctx.set_chunk_sites(32)
+        ctx.set_workspace_limit(60 * 65536 * 2)  # ~60 rows of 64 KiB for each of the two groups: 150 sites do not fit
+        _assert_records_equal(ctx.decode_ibd(model, _pairs_array(pairs), groups),
+                              O.decode_pairs_ibd(pm, folded, pairs, batch_size=64))
+        assert ctx.info()["max_chunks"] > 1
     ctx.close()
 
 
