@@ -14,12 +14,11 @@ HIPCC_FLAGS = [
     "-ffp-contract=off",  # parity: the reference path has no fused multiply-add
     "-fno-slp-vectorize",  # packed-f32 SLP of the k-recurrences costs more moves than it saves
     "-fPIC", "-shared",
-    "-Wno-pass-failed",  # the generic (runtime-K) instantiation cannot unroll its k-loops, by design
+    "-Wno-pass-failed",  # (loops the unroller gives up on: segment ages walk memory with real loops, by design)
 ]
 
 # family members of the library (csrc/fsmc_instances.h): one translation unit each, compiled in parallel
-KT_MEMBERS = [0, 16, 32, 48, 64, 69, 80, 96, 112, 128]
-Q4_MEMBERS = [48, 64]
+KT_MEMBERS = [16, 32, 48, 64, 69, 80, 96, 112, 128]
 W2_MEMBERS = [48, 64]
 OBJ_DIR = os.path.join(CSRC, "obj")
 
@@ -63,7 +62,6 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     units = [("capi", os.path.join(CSRC, "fsmc_capi.hip"), []),
              ("idsort", os.path.join(CSRC, "fsmc_identify_sort.hip"), [])]
     units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"]) for k in KT_MEMBERS]
-    units += [(f"q4_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_Q4={k}"]) for k in Q4_MEMBERS]
     units += [(f"w2_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_W2={k}"]) for k in W2_MEMBERS]
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
     pending = list(units)

@@ -184,7 +184,8 @@ class Context:
         return v.value
 
     def last_kernel(self) -> int:
-        """Family member of the last launch: KT > 0 lane-per-pair, -KQ four lanes per pair, 0 runtime-K kernel."""
+        """Kernel of the last launch: KT (16 ... 128) = the lane-per-pair family member, 1000 + KH (1048, 1064) = the
+        four-waves-per-group kernel with KH states per wave."""
         v = C.c_int32(0)
         self._check(self._L.fsmc_ctx_last_kernel(self._h, C.byref(v)))
         return v.value

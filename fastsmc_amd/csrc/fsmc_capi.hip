@@ -88,7 +88,7 @@ struct fsmc_ctx {
   uint32_t chunkSites = 0; // 0 = automatic
   uint32_t betaStride = 0; // 0 = automatic (2 where the kernel exists), 1 = store every beta row
   int lastStride = 1;
-  int lastMember = 0; // family member of the last launch: KT of the lane-per-pair kernel, -KQ of the q4 kernel
+  int lastMember = 0; // member of the last launch: KT of the lane-per-pair kernel, 1000 + KH of the wave-group kernel
 
   // The queues an IBD decode's waves pull from (fsmc_decode_ibd_launch): built from the uploaded groups once per
   // work list and budget, longest window first.
@@ -284,22 +284,12 @@ bool halfAvailable(int mode, const fsmc_model* m)
   return mode == kModeIbd && !m->sequence && halfBuilt(familyMember(m));
 }
 
-// The wide-model kernel (four lanes per pair, fsmc_kernels_q4.h): 80 < K <= 256, array mode, IBD, per-pair and dump
-// consumers.  fsmc_model_create pads such a model's rows to KP = 192 or 256 floats = 4 x the states per lane.
-bool quarterLanes(int mode, const fsmc_model* m)
-{
-  return familyMember(m) == 0 && m->K > 69 && m->K <= 4 * kQ4MaxStates && !m->sequence &&
-         (mode == kModeIbd || mode == kModeDump || mode == kModePerPair) &&
-         (m->KP == 192 || m->KP == 256);
-}
-
-// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): the IBD, dump and sums consumers
-// of the same models.  FSMC_WIDE_Q4 in the environment keeps the four-lanes-per-pair kernel (A/B measurements, tests).
+// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): 128 < K <= 256, every consumer,
+// array and sequence mode.  fsmc_model_create pads such a model's rows to KP = 192 or 256 floats = 4 x the states per wave.
 bool waveGroups(int mode, const fsmc_model* m)
 {
   return familyMember(m) == 0 && m->K > 128 && m->K <= 256 && (m->KP == 192 || m->KP == 256) &&
-         (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair) &&
-         (m->sequence || std::getenv("FSMC_WIDE_Q4") == nullptr);
+         (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair);
 }
 
 template <int KH, bool SEQ> KernelFn pickWaveGroupKernelOf(int mode, bool track)
@@ -326,17 +316,6 @@ unsigned blockThreads(int mode, const fsmc_model* m)
   return waveGroups(mode, m) ? (unsigned)(kW2NW * kWave) : (unsigned)kWave;
 }
 
-template <int KQ> KernelFn pickQuarterKernel(int mode, bool track)
-{
-  if (mode == kModeIbd) {
-    return track ? decode_kernel_q4<KQ, kModeIbd, true> : decode_kernel_q4<KQ, kModeIbd, false>;
-  }
-  if (mode == kModePerPair) {
-    return decode_kernel_q4<KQ, kModePerPair, false>;
-  }
-  return decode_kernel_q4<KQ, kModeDump, false>;
-}
-
 KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false)
 {
   if (waveGroups(mode, m)) {
@@ -346,13 +325,6 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
     m->ctx->lastMember = 1000 + m->KP / kW2NW; // 1048 / 1064: four waves per group, 48 / 64 states per wave
     return m->KP == 192 ? pickWaveGroupKernel<48>(mode, track, m->sequence != 0)
                         : pickWaveGroupKernel<64>(mode, track, m->sequence != 0);
-  }
-  if (quarterLanes(mode, m)) {
-    if (mode == kModeIbd) {
-      m->ctx->lastStride = 1;
-    }
-    m->ctx->lastMember = -(m->KP / 4);
-    return m->KP == 192 ? pickQuarterKernel<48>(mode, track) : pickQuarterKernel<64>(mode, track);
   }
   const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1; // (also with two half-groups per wave)
   if (mode == kModeIbd) {
@@ -380,7 +352,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
   case 128:
     return pickMember<128>(mode, track, m->sequence, half, dual);
   default:
-    return pickMember<0>(mode, track, m->sequence, false);
+    return nullptr; // (no such model passes fsmc_model_create: K <= 128 has a member, 128 < K <= 256 the wave-group kernel)
   }
 }
 
@@ -401,6 +373,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
                DevBuf* ws = nullptr)
 {
   const std::vector<fsmc_group>& list = items ? *items : ctx->hGroups;
+  if (!fn) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "no kernel for this model");
+  }
   int blocksPerCU = 0;
   FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fn, (int)blockThreads(mode, m), 0));
   if (blocksPerCU < 1) {
@@ -415,10 +390,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
       blocksPerCU = v;
     }
   }
-  const bool w2 = waveGroups(mode, m);          // a workgroup of four waves takes a group, lane = pair
-  const bool q4 = !w2 && quarterLanes(mode, m); // a wave takes a quarter of a group and holds 64 states per lane
+  const bool w2 = waveGroups(mode, m); // a workgroup of four waves takes a group, lane = pair
   size_t slots = (size_t)ctx->nCU * blocksPerCU;
-  slots = std::min(slots, q4 ? 4 * list.size() : list.size());
+  slots = std::min(slots, list.size());
   if (slots < 1) {
     slots = 1;
   }
@@ -427,9 +401,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     const size_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
     L = std::max<size_t>(L, aEnd - g.from);
   }
-  // float4 per lane of a stored K-vector: q4 lanes hold KP/4 states; a padded family member stores its ghosts too
+  // float4 per lane of a stored K-vector: a padded family member (and the wave-group kernel) stores its ghosts too
   const int member = familyMember(m);
-  const size_t K4 = w2 ? (size_t)m->KP / 4 : q4 ? (size_t)m->KP / 16 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
+  const size_t K4 = w2 ? (size_t)m->KP / 4 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / share;
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
@@ -804,7 +778,7 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   m->K = d->K;
   m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
   if (d->K > 128) {
-    // wide models: four lanes per pair hold KP/4 states each (fsmc_kernels_q4.h); the padding states are ghosts
+    // wide models: four waves per group hold KP/4 states each (fsmc_kernels_w2.h); the padding states are ghosts
     m->KP = d->K <= 128 ? 128 : d->K <= 192 ? 192 : 256;
   }
   m->S = d->S;
@@ -1429,10 +1403,6 @@ int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_
   }
   FSMC_HIP(ctx, hipMemcpyAsync(ctx->aux.p, offsets.data(), offsets.size() * sizeof(size_t), hipMemcpyHostToDevice,
                                ctx->stream));
-  if (quarterLanes(kModeDump, m) && !waveGroups(kModeDump, m)) {
-    // quarters of a group that hold no pair are skipped by the kernel: their lanes must read as zero
-    FSMC_HIP(ctx, hipMemsetAsync(ctx->out.p, 0, total * sizeof(float), ctx->stream));
-  }
   KParams p;
   fillParams(ctx, m, plan, 0, p);
   p.dumpOut = (float*)ctx->out.p;

@@ -1,6 +1,6 @@
 // fsmc_inst.hip -- one family member's kernel instantiations (see fsmc_instances.h).
-// Compiled with -DFSMC_INSTANCE_KT=<n> (lane-per-pair member), -DFSMC_INSTANCE_Q4=<n> (states per lane of the
-// four-lanes-per-pair kernel) or -DFSMC_INSTANCE_W2=<n> (states per wave of the four-waves-per-group kernel); fastsmc_amd/build.py drives one hipcc per member, in parallel.
+// Compiled with -DFSMC_INSTANCE_KT=<n> (lane-per-pair member) or -DFSMC_INSTANCE_W2=<n> (states per wave of the
+// four-waves-per-group kernel); fastsmc_amd/build.py drives one hipcc per member, in parallel.
 #include "fsmc_instances.h"
 
 namespace fsmc
@@ -18,11 +18,9 @@ FSMC_DEFINE_KT_DUAL_HALF(FSMC_INSTANCE_KT)
 #else
 static_assert(!halfBuilt(FSMC_INSTANCE_KT), "keep halfBuilt() and this list in step");
 #endif
-#elif defined(FSMC_INSTANCE_Q4)
-FSMC_Q4_KERNELS(FSMC_DEFINE_Q4, FSMC_INSTANCE_Q4)
 #elif defined(FSMC_INSTANCE_W2)
 FSMC_W2_KERNELS(FSMC_DEFINE_W2, FSMC_INSTANCE_W2)
 #else
-#error "define FSMC_INSTANCE_KT, FSMC_INSTANCE_Q4 or FSMC_INSTANCE_W2"
+#error "define FSMC_INSTANCE_KT or FSMC_INSTANCE_W2"
 #endif
 } // namespace fsmc

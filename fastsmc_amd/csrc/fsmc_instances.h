@@ -1,20 +1,21 @@
 // fsmc_instances.h -- the kernel instantiations of libfastsmc_hip.so and where each is compiled.
 //
-// The decode kernels are templates (fsmc_kernels.h, fsmc_kernels_q4.h); every instantiation is a fully unrolled
-// kernel of several thousand instructions, so they are compiled in separate translation units, in parallel:
-// fsmc_inst.hip is built once per family member (-DFSMC_INSTANCE_KT=<n> / -DFSMC_INSTANCE_Q4=<n>) and defines the
-// instantiations of that member; fsmc_capi.hip only sees the declarations below and picks a function pointer.
+// The decode kernels are templates (fsmc_kernels.h, fsmc_kernels_w2.h); every instantiation is a fully unrolled kernel
+// of several thousand instructions, so they are compiled in separate translation units, in parallel: fsmc_inst.hip is
+// built once per member (-DFSMC_INSTANCE_KT=<n> / -DFSMC_INSTANCE_W2=<n>) and defines the instantiations of that
+// member; fsmc_capi.hip only sees the declarations below and picks a function pointer.
 //
-// Lane-per-pair family (decode_kernel<KT, MODE, TRACK, SEQ, HALF>):
+// Lane-per-pair family (decode_kernel<KT, MODE, TRACK, SEQ, HALF, DUAL>), one wave per group:
 //   KT = 69               the 69-state models of the reference's decoding-quantities files, no padding
 //   KT = 16, 32, 48, 64, 80   every other model with K <= 80: padded with ghost states to the next member
 //   KT = 96, 112, 128     80 < K <= 128: the same kernel with one wave per SIMD (512 registers a lane)
-//   KT = 0                runtime K (128 < K <= 256 in the modes the four-lanes-per-pair kernel does not have)
-// Four-lanes-per-pair kernel (decode_kernel_q4<KQ, MODE, TRACK>): 128 < K <= 256, KQ = 48, 64 states per lane.
+// Wave-group kernel (decode_kernel_w2<KH, MODE, TRACK, SEQ>), lane = pair and four waves per group: 128 < K <= 256,
+//   KH = 48, 64 states per wave.
+// (The runtime-K instantiation KT = 0 and the four-lanes-per-pair kernel of earlier builds are gone: every model of at
+//  most 256 states, in every mode, runs one of the kernels above.)
 #pragma once
 
 #include "fsmc_kernels.h"
-#include "fsmc_kernels_q4.h"
 #include "fsmc_kernels_w2.h"
 
 namespace fsmc
@@ -40,11 +41,6 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_KT_HALF_KERNELS(X, KT)                                                                                    \
   X(KT, kModeIbd, true, false, true)                                                                                   \
   X(KT, kModeIbd, false, false, true)
-#define FSMC_Q4_KERNELS(X, KQ)                                                                                         \
-  X(KQ, kModeIbd, true)                                                                                                \
-  X(KQ, kModeIbd, false)                                                                                               \
-  X(KQ, kModeDump, false)                                                                                              \
-  X(KQ, kModePerPair, false)
 
 #define FSMC_DECLARE_KT(KT, MODE, TRACK, SEQ, HALF)                                                                    \
   extern template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
@@ -79,15 +75,12 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_DECLARE_W2(KH, MODE, TRACK, SEQ)                                                                          \
   extern template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ>(const KParams);
 #define FSMC_DEFINE_W2(KH, MODE, TRACK, SEQ) template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ>(const KParams);
-#define FSMC_DECLARE_Q4(KQ, MODE, TRACK) extern template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
-#define FSMC_DEFINE_Q4(KQ, MODE, TRACK) template __global__ void decode_kernel_q4<KQ, MODE, TRACK>(const KParams);
 
 // every member of the library (build.py compiles fsmc_inst.hip once for each entry of these two lists)
-#define FSMC_ALL_KT(Y) Y(0) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80) Y(96) Y(112) Y(128)
-#define FSMC_ALL_Q4(Y) Y(48) Y(64)
+#define FSMC_ALL_KT(Y) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80) Y(96) Y(112) Y(128)
 #define FSMC_ALL_W2(Y) Y(48) Y(64)
 
-#if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_Q4) && !defined(FSMC_INSTANCE_W2)
+#if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_W2)
 #define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)
 FSMC_ALL_KT(FSMC_DECLARE_MEMBER)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 16)
@@ -115,8 +108,6 @@ FSMC_DECLARE_KT_DUAL(80)
 FSMC_DECLARE_KT_DUAL(96)
 FSMC_DECLARE_KT_DUAL(112)
 FSMC_DECLARE_KT_DUAL(128)
-#define FSMC_DECLARE_Q4_MEMBER(KQ) FSMC_Q4_KERNELS(FSMC_DECLARE_Q4, KQ)
-FSMC_ALL_Q4(FSMC_DECLARE_Q4_MEMBER)
 #define FSMC_DECLARE_W2_MEMBER(KH) FSMC_W2_KERNELS(FSMC_DECLARE_W2, KH)
 FSMC_ALL_W2(FSMC_DECLARE_W2_MEMBER)
 #endif

@@ -198,7 +198,7 @@ def test_binary_output_round_trip(files, small_problem, tmp_path):
 
 
 def test_fastsmc_run_wide_model_matches_oracle_text(small_problem, tmp_path):
-    """The same end-to-end run with a 100-state model: routed to the wide-model kernel (four lanes per pair, 28 ghost
+    """The same end-to-end run with a 100-state model: routed to the 112-state member of the kernel family (12 ghost
     states) through the ordinary host path -- files, Data, HMM, FastSMC.run(), text output."""
     sp = dict(small_problem)
     sp["tables"] = synth.make_model_tables(100)

@@ -1,11 +1,8 @@
 """Models other than K = 69 against the oracle, all output modes.  K <= 80 runs the lane-per-pair kernel compiled for
 the next family member (16, 32, 48, 64, 80 states with two waves per SIMD, 96, 112, 128 with one; the padding states are
 ghosts -- K = 2, 5, 16 exactly, 17, 33, 50, 64 exactly, 65, 70, 80 exactly, 81, 100, 128 exactly); 128 < K <= 256 the
-wide-model kernels, ghost-padded (K = 130, 192 exactly, 200, 256 exactly): four waves per group with lane = pair for
-the IBD, dump and sums consumers, four lanes per pair for the per-pair consumer (and for everything but the sums with
-FSMC_WIDE_Q4 in the environment, when the sums come from the runtime-K kernel).  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
-import os
-
+wide-model kernel, ghost-padded (K = 130, 192 exactly, 200, 256 exactly): four waves per group with lane = pair, every
+consumer.  Every launch is checked for the family member it ran (fsmc_ctx_last_kernel)."""
 import numpy as np
 import pytest
 
@@ -27,14 +24,12 @@ def _problem(K, n_hap=64, S=200, seed=11):
 
 def _member(K, consumer="ibd"):
     """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; beyond, the four-waves-per-group
-    kernel (1000 + states per wave), or the four-lanes-per-pair kernel (-states per lane) with FSMC_WIDE_Q4 in the
-    environment."""
+    kernel (1000 + states per wave)."""
     if K == 69:
         return 69
     if K <= 128:
         return (K + 15) // 16 * 16
-    kq = 48 if K <= 192 else 64
-    return -kq if os.environ.get("FSMC_WIDE_Q4") else 1000 + kq
+    return 1000 + (48 if K <= 192 else 64)
 
 
 def _stride(K):
@@ -73,7 +68,7 @@ def test_generic_kernel_matches_oracle(K):
     np.testing.assert_array_equal(mean, wmean)
     np.testing.assert_array_equal(mp, wmap)
     s, _ = ctx.decode_sums(model)  # (K = 256 included: the transposition tile is sized for it)
-    assert ctx.last_kernel() == (0 if K > 128 and os.environ.get("FSMC_WIDE_Q4") else _member(K))
+    assert ctx.last_kernel() == _member(K)
     wsum = np.zeros((pm.S, pm.K), np.float32)
     O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
     np.testing.assert_array_equal(s, wsum)
@@ -138,14 +133,6 @@ def test_wide_model_scan_thresholds_that_reach_the_upper_waves(K, time):
             np.testing.assert_array_equal(got["post_mean"], want["postMean"])
             np.testing.assert_array_equal(got["map"], want["map"])
     ctx.close()
-
-
-@pytest.mark.parametrize("K", [130, 192, 200, 256])
-def test_wide_models_on_the_four_lanes_kernel_too(K, monkeypatch):
-    """FSMC_WIDE_Q4 keeps the four-lanes-per-pair kernel for the IBD and dump consumers of 128 < K <= 256 (the kernel the
-    per-pair consumer always uses): same bits."""
-    monkeypatch.setenv("FSMC_WIDE_Q4", "1")
-    test_generic_kernel_matches_oracle(K)
 
 
 def test_too_many_states_is_rejected():

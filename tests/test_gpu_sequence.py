@@ -206,7 +206,7 @@ def test_asmc_api_in_sequence_mode(seq_problem, tmp_path):
 
 
 def test_sequence_mode_with_a_wide_model(seq_problem):
-    """A 100-state model in sequence mode: rows padded to 128 floats (the wide-model padding) on the runtime-K kernel."""
+    """A 100-state model in sequence mode: the 112-state member of the lane-per-pair family (12 ghost states)."""
     sp = seq_problem
     tables = synth.make_model_tables(100)
     haps = sp["haps"]

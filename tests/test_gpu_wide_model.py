@@ -1,7 +1,7 @@
-"""The wide-model kernel (K = 256, four lanes per pair; fastsmc_amd/csrc/fsmc_kernels_q4.h) against the oracle,
-bit for bit: state thresholds inside the first quarter of the states, across two and across three quarters (the scan's
-sum then crosses lanes), groups whose last quarter is ragged or empty, sub-windows with scan windows inside them, the
-checkpoint/recompute layout, with and without segment ages, and the posterior dump."""
+"""The wide-model kernel (K = 256: lane = pair, four waves per group; fastsmc_amd/csrc/fsmc_kernels_w2.h) against the
+oracle, bit for bit: state thresholds inside the first quarter of the states, across two and across three quarters (the
+scan's sum then crosses waves), ragged groups, sub-windows with scan windows inside them, the checkpoint/recompute
+layout, with and without segment ages, and the posterior dump."""
 import numpy as np
 import pytest
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static instruction mix of the decode kernels: compiles one family member (csrc/fsmc_inst.hip, default
--DFSMC_INSTANCE_KT=69; set ISA_MEMBER=kt<n> or q4_<n>) to gfx950 assembly (device only) and counts instructions per
+-DFSMC_INSTANCE_KT=69; set ISA_MEMBER=kt<n> or w2_<n>) to gfx950 assembly (device only) and counts instructions per
 kernel instantiation.  Usage: tools/isa_stats.py [filter] [-- extra hipcc flags]"""
 import collections
 import os
@@ -22,7 +22,7 @@ flt = args[0] if args else "ILi69ELi0E"
 out = "/tmp/fsmc_isa.s"
 flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
 member = os.environ.get("ISA_MEMBER", "kt69")
-define = "-DFSMC_INSTANCE_Q4=" + member[3:] if member.startswith("q4_") else "-DFSMC_INSTANCE_KT=" + member[2:]
+define = "-DFSMC_INSTANCE_W2=" + member[3:] if member.startswith("w2_") else "-DFSMC_INSTANCE_KT=" + member[2:]
 subprocess.run(["hipcc", *flags, *extra, define, "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o",
                 out, os.path.join(ROOT, "fastsmc_amd/csrc/fsmc_inst.hip")], check=True)
 txt = open(out).read()

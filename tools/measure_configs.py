@@ -3,7 +3,8 @@
 never as bench.py's `value`):
   c1_ibd / c1_sums   300 haplotypes x 6760 sites, K = 69, all 44 850 pairs: IBD consumer, and the sum-over-pairs
                      consumer of the reference's own published timing (time_regression.py: 51.97 s on one CPU thread)
-  k256 k192 k128 k100  wide models (four lanes per pair), reduced C4 shape: 600 haplotypes x 3000 sites, all pairs
+  k256 k192 k128 k100  wide models (four waves per group beyond 128 states), reduced C4 shape: 600 haplotypes x 3000
+                     sites, all pairs
   hashing            FastSMC.run() end to end with the hashing pre-filter on, C2-sized files (parse + identify + decode +
                      write)
   short              the IBD decode alone on 60 000 hashing-style batches (32 pairs, 320-5504-site windows): the C5 regime

@@ -26,7 +26,6 @@ echo "family done"
 cp $(find $OUT/identify_trace -name "*kernel_stats.csv" | head -1) $OUT/identify_kernel_stats.csv 2>/dev/null
 python3 tools/measure_configs.py hashing > $OUT/hashing.json 2> $OUT/hashing.err
 python3 tools/measure_configs.py seq seq100 > $OUT/sequence.jsonl 2> $OUT/sequence.err
-FSMC_WIDE_Q4=1 python3 tools/measure_configs.py k256 k192 > $OUT/wide_q4.jsonl 2> $OUT/wide_q4.err
 python3 tools/measure_configs.py k256 k192 > $OUT/wide_w2.jsonl 2> $OUT/wide_w2.err
 echo "identify done"
 python3 tools/measure_configs.py run_c2 > $OUT/run_c2.json 2> $OUT/run_c2.err
