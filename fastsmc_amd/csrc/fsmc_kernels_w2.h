@@ -30,10 +30,17 @@ namespace fsmc
 constexpr int kW2NW = 4;    // waves per group
 // mailbox rows (64 floats each): carries of the recurrences per boundary, partial sums per wave
 constexpr int kW2RowT = 0, kW2RowBU = 3, kW2RowBL = 6, kW2RowC = 0, kW2RowAU = 3; // (+ boundary 0..2)
+#if defined(FSMC_W2_DIAG_OLD_LDS) // layout experiment
+constexpr int kW2RowStep = 9, kW2RowComb = 13, kW2RowLevel = 21;
+constexpr int kW2RowScan = 17;
+constexpr int kW2RowMean = kW2RowT;
+constexpr int kW2Mail = 23;
+#else
 constexpr int kW2RowStep = 9, kW2RowComb = 13, kW2RowLevel = 17;
 constexpr int kW2RowScan = kW2RowStep; // (the scan's partial sums follow the combine: the step's rows are free then)
 constexpr int kW2RowMean = kW2RowT;    // (kModePerPair: likewise the carries' rows)
 constexpr int kW2Mail = 19;
+#endif
 constexpr int kWBF = 8;    // ... and of the forward pass (four tables at a time)
 constexpr int kWBWide = 8;  // ... of the passes with two operand rows (16-state blocks measured 4 % slower at 64 states per wave: spills)
 constexpr int kWB = 8;     // states per operand block of the backward passes here (two waves' roles in one kernel leave
@@ -601,7 +608,8 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
     };
     // this wave's states of the three emission rows of site q into its ring slot (q & 1), by LDS-DMA
     auto stageEmis = [&](const int qIn) {
-      const int q = __builtin_amdgcn_readfirstlane(qIn); // (wave-uniform by construction: the ring slot is an M0 value)
+      // (wave-uniform by construction: the ring slot is an M0 value -- the sequence-mode call sites need it spelled out)
+      const int q = SEQ ? __builtin_amdgcn_readfirstlane(qIn) : qIn;
 #pragma unroll
       for (int i = 0; i < NLE; ++i) {
         const int idx = lane + i * kWave; // class * K4H + k4
