@@ -99,6 +99,7 @@ struct fsmc_ctx {
     bool valid = false;
     bool dual = false;    // items/unions in use: two half-groups per wave
     bool reordered = false; // rest is in use (a reordered copy or subset of the uploaded groups)
+    bool alone = false;     // every group rides in the paired kernel: it has the whole workspace
     std::vector<fsmc_group> items, unions, rest;
   } q;
   uint64_t worklistSerial = 0;
@@ -1017,17 +1018,40 @@ bool buildDualItems(const std::vector<fsmc_group>& groups, uint32_t maxLen, std:
   if (unions.empty()) {
     return false;
   }
-  // the pairs were made from the shortest class up: the waves pull them longest first
-  std::reverse(unions.begin(), unions.end());
-  for (size_t i = 0, j = items.size() - 2; i < j; i += 2, j -= 2) {
-    std::swap(items[i], items[j]);
-    std::swap(items[i + 1], items[j + 1]);
-  }
+  // A half-full group that found no partner but fits the layout rides in the same kernel as an item of its own (B
+  // empty): one queue, longest window first, instead of a second kernel whose long windows finish whenever the
+  // hardware got round to starting them.  What does not fit (more than 32 pairs, a window beyond the budget) is `rest`.
   for (size_t g = 0; g < groups.size(); ++g) {
-    if (!taken[g]) {
-      rest.push_back(groups[g]);
+    if (taken[g]) {
+      continue;
+    }
+    const fsmc_group& a = groups[g];
+    if (a.n_pairs <= 32 && a.to - a.from <= maxLen) {
+      fsmc_group none = a;
+      none.n_pairs = 0;
+      items.push_back(a);
+      items.push_back(none);
+      unions.push_back(a);
+    } else {
+      rest.push_back(a);
     }
   }
+  // the waves pull the items longest first
+  std::vector<uint32_t> order(unions.size());
+  for (size_t i = 0; i < order.size(); ++i) {
+    order[i] = (uint32_t)i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    return unions[x].scan_to - unions[x].from > unions[y].scan_to - unions[y].from;
+  });
+  std::vector<fsmc_group> items2(items.size()), unions2(unions.size());
+  for (size_t i = 0; i < order.size(); ++i) {
+    unions2[i] = unions[order[i]];
+    items2[2 * i] = items[2 * order[i]];
+    items2[2 * i + 1] = items[2 * order[i] + 1];
+  }
+  items.swap(items2);
+  unions.swap(unions2);
   return true;
 }
 
@@ -1079,7 +1103,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   // (decode_kernel<..., DUAL>, with beta stride 2 where that is built); the other groups one per wave, in a kernel that
   // runs beside it.
   KernelFn fnDual = nullptr;
-  uint64_t maxLen = 0;
+  uint64_t maxLen = 0, maxLenAlone = 0; // pairing budgets: beside a second kernel (half the workspace) / on its own
   if (ctx->pairing != 0 && !m->sequence && familyMember(m) > 0) {
     fnDual = pickKernel(kModeIbd, track, m, true);
     int blocksPerCU = 0;
@@ -1090,6 +1114,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     const size_t rowsAvail = (size_t)(limit / (vecBytes * slots));
     const bool halfDual = halfAvailable(kModeIbd, m) && ctx->betaStride != 1; // a stored row serves two sites
     maxLen = rowsAvail > 16 ? std::min<size_t>((rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
+    maxLenAlone = 2 * rowsAvail > 16 ? std::min<size_t>((2 * rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
   }
   fsmc_ctx::IbdQueues& q = ctx->q;
   if (!q.valid || q.serial != ctx->worklistSerial || q.maxLen != maxLen || q.pairing != ctx->pairing) {
@@ -1097,8 +1122,18 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     q.items.clear();
     q.unions.clear();
     q.rest.clear();
-    q.dual = maxLen > 0 && buildDualItems(ctx->hGroups, (uint32_t)maxLen, q.items, q.unions, q.rest);
+    // first with the whole workspace: if every group then rides in the paired kernel there is no second kernel to share with
+    q.dual = maxLenAlone > 0 && buildDualItems(ctx->hGroups, (uint32_t)maxLenAlone, q.items, q.unions, q.rest);
+    q.alone = q.dual && q.rest.empty();
+    if (q.dual && !q.alone) {
+      q.items.clear();
+      q.unions.clear();
+      q.rest.clear();
+      q.dual = maxLen > 0 && buildDualItems(ctx->hGroups, (uint32_t)maxLen, q.items, q.unions, q.rest);
+    }
     if (!q.dual) {
+      q.items.clear();
+      q.unions.clear();
       q.rest = ctx->hGroups;
     }
     q.reordered = longestFirst(q.rest) || q.dual;
@@ -1123,7 +1158,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   const bool beside = q.dual && haveRest;
   LaunchPlan planDual, plan;
   if (q.dual) {
-    rc = planLaunch(ctx, m, kModeIbd, fnDual, planDual, &q.unions, true, 2);
+    rc = planLaunch(ctx, m, kModeIbd, fnDual, planDual, &q.unions, true, q.alone ? 1 : 2);
     if (rc != FSMC_OK) {
       return rc;
     }

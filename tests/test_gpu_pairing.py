@@ -3,7 +3,8 @@ pairs share a wave, each lane decoded over its OWN group's decode and scan windo
 the unpaired run (and of the oracle): different windows in the two halves, a half that starts later / ends earlier than
 the other, one-site windows, ragged halves, segment ages on and off, several family members, both beta strides.  Groups that do not pair
 (more than 32 pairs, or a window too long for the paired kernel's single-chunk layout) run in a second kernel of the
-same decode and land in the same record list."""
+same decode and land in the same record list; half-full groups that find no partner but fit ride in the paired kernel as
+items of their own."""
 import numpy as np
 import pytest
 
@@ -117,9 +118,10 @@ def test_windows_too_long_to_pair_run_in_the_second_kernel(small_problem):
     ctx = capi.Context(0)
     model = ctx.create_model(pm)
     ctx.upload_haps(small_problem["bits"], S)
-    # the pairing budget is what a FULL machine of resident waves could hold in half of the workspace: ~200 rows of
-    # 18 float4 x 64 lanes per wave on 256 CUs x 8 waves -- enough for the 80-site windows, not for the 640-site ones
-    ctx.set_workspace_limit(2 * 200 * 18 * 64 * 16 * 256 * 8)
+    # the pairing budget is what a FULL machine of resident waves could hold: ~200 rows of 18 float4 x 64 lanes per wave on
+    # 256 CUs x 8 waves (half of that beside a second kernel) -- with beta stride 2 enough for windows of up to 387 sites,
+    # not for the 640-site ones
+    ctx.set_workspace_limit(200 * 18 * 64 * 16 * 256 * 8)
     plain, n0 = _run(ctx, model, pairs, wins, flags, pairing=0)
     paired, n1 = _run(ctx, model, pairs, wins, flags, pairing=1)
     ctx.close()
