@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace fsmc_host
 {
@@ -212,13 +213,33 @@ void runHashing(const Data& data, const DecodingParams& params, HMM& hmm)
   HashingPrefilter pf(data, params);
   const std::vector<HashingCandidate> all = pf.runOnDevice(hmm.engine());
   // sharded: every rank runs the identification step and decodes a contiguous range of the resulting batches, so
-  // each batch has the composition -- hence the window -- of a single-device run
+  // each batch has the composition -- hence the window -- of a single-device run.  The ranges have equal pair-site
+  // WEIGHT, not equal batch counts (the windows differ in length): the reference's own range rule total*r/R
+  // (HMM.cpp:319-321) applied to the running weight, cut at batch boundaries.
   size_t first = 0, last = all.size();
   if (hmm.shardWorld() > 1) {
-    const auto B = static_cast<unsigned long long>(hmm.batchSize());
-    const auto [lo, hi] = hmm.shardBatchRange((all.size() + B - 1) / B);
-    first = std::min<size_t>(all.size(), lo * B);
-    last = std::min<size_t>(all.size(), hi * B);
+    const size_t B = static_cast<size_t>(hmm.batchSize());
+    const size_t nBatches = (all.size() + B - 1) / B;
+    std::vector<unsigned long long> upTo(nBatches + 1, 0ull); // pair-sites of the batches before batch i
+    for (size_t b = 0; b < nBatches; ++b) {
+      unsigned lo = ~0u, hi = 0u;
+      const size_t e = std::min(all.size(), (b + 1) * B);
+      for (size_t i = b * B; i < e; ++i) {
+        lo = std::min(lo, all[i].from);
+        hi = std::max(hi, all[i].to);
+      }
+      upTo[b + 1] = upTo[b] + static_cast<unsigned long long>(e - b * B) * (hi - lo + 1);
+    }
+    const auto world = static_cast<unsigned long long>(hmm.shardWorld());
+    auto cut = [&](unsigned long long r) { // first batch whose preceding weight reaches total * r / world
+      const unsigned long long want = upTo[nBatches] / world * r + upTo[nBatches] % world * r / world;
+      return static_cast<size_t>(std::lower_bound(upTo.begin(), upTo.end(), want) - upTo.begin());
+    };
+    const auto r = static_cast<unsigned long long>(hmm.shardRank());
+    const size_t bLo = r == 0 ? 0 : std::min(cut(r), nBatches);
+    const size_t bHi = r + 1 == world ? nBatches : std::min(cut(r + 1), nBatches);
+    first = std::min(all.size(), bLo * B);
+    last = std::min(all.size(), std::max(bLo, bHi) * B);
   }
   for (size_t i = first; i < last; ++i) {
     hmm.decodeFromHashing(all[i].hapA, all[i].hapB, all[i].from, all[i].to);
