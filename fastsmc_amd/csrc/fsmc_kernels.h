@@ -37,7 +37,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMaxGenericK = 256; // upper bound on K for the generic (runtime-K) kernel
+constexpr int kMaxGenericK = 256; // upper bound on K for the generic (runtime-K) steps -- KT = 0, no longer instantiated
+                                  // in the library: kept for the -DFSMC_NO_PK comparison builds
 
 enum Mode : int { kModeIbd = 0, kModeDump = 1, kModePerPair = 2, kModeSums = 3 };
 

@@ -2,10 +2,10 @@
 // lane = pair and SEVERAL WAVES per group.
 //
 // A lane cannot hold the K-vectors of a 256-state model (2 x 256 registers is the whole file), and splitting a pair over
-// lanes (fsmc_kernels_q4.h) leaves three quarters of a wave idle in every recurrence.  Here a workgroup of NW = 4 waves
+// four lanes (the kernel this one replaced) leaves three quarters of a wave idle in every recurrence.  Here a workgroup of NW = 4 waves
 // decodes one group of <= 64 pairs: lane l of EVERY wave is pair l, wave h holds states [KH*h, KH*h + KH) (KH = 48 or 64)
 // -- every instruction of every wave serves 64 pairs, and a wave's two K-vectors are 2 x 64 registers (two waves per
-// SIMD, nothing spilled).  The first-order recurrences cross the boundaries between the waves through a mailbox in LDS
+// SIMD).  The first-order recurrences cross the boundaries between the waves through a mailbox in LDS
 // and workgroup barriers; they come in opposite pairs, which pipeline against each other over NW phases:
 //   backward step   phase p: wave NW-1-p runs BU (descending) over its states | wave p runs BL (ascending) over its states
 //   forward step    phase p: wave NW-1-p runs the suffix sums alphaC (desc.)   | wave p runs AU (ascending)
@@ -15,9 +15,11 @@
 // operands, in the same order, as in the reference (HMM.cpp:799-830, 957-1016, HmmUtils.cpp:102-151): bit-identical.
 // Operands are wave-uniform (each wave its own part of the table rows): scalar loads one block ahead, as in
 // fsmc_kernels.h; each wave stages the emission values of its own states in its own two-site LDS ring and lands its own
-// part of the next beta row by LDS-DMA.  Beta stride 1, array mode; consumers: IBD scan (with segment ages) and the
-// posterior dump.  Ghost padding as in fsmc_kernels_q4.h (rows padded to KP = NW*KH floats; ghosts only occur in the
-// upper half, whose backward step multiplies by the 1/0 mask row).
+// part of the next beta row by LDS-DMA.  Beta stride 1; array mode and sequence mode; consumers: IBD scan (with segment
+// ages), posterior dump, sums over pairs, per-pair mean / MAP rows.  Ghost padding: rows padded to KP = NW*KH floats with
+// zero table, emission and prior entries -- ghost values stay exactly +0 through every operation, except that beta' of a
+// ghost is BL: ghosts only occur in the upper half, whose backward step multiplies by the 1/0 mask row (x * 1.0f is
+// exact).
 #pragma once
 
 #include <type_traits>

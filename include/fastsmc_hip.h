@@ -127,7 +127,7 @@ int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes);
 int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites);
 /* Tuning: beta stride of the IBD decode.  1 = every beta row of a chunk goes through HBM (8K bytes per pair-site);
  * 2 = every second row does and the alpha sweep recomputes the others from their successor (4K bytes per
- * pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (array mode, K <= 69), else 1.
+ * pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (array mode; K <= 69 and 81 ... 128), else 1.
  * Results do not depend on it.  fsmc_ctx_last_beta_stride reports what the last IBD launch used. */
 int fsmc_ctx_set_beta_stride(fsmc_ctx* ctx, uint32_t stride);
 int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
@@ -136,13 +136,14 @@ int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
 int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_chunks, int32_t* n_slots);
 /* Two half-groups per wavefront.  A group of at most 32 pairs (a hashing-mode batch of the reference's default size)
  * fills half a wave; with pairing = 1 (default) the IBD decode puts two such groups with nearby windows on one wave,
- * each lane still decoded over its own group's windows (results do not depend on it).  0 = never.
+ * each lane still decoded over its own group's windows (results do not depend on it); half-full groups that find no
+ * partner ride in the same kernel as items of their own.  0 = never.
  * fsmc_ctx_last_items: wave work items of the last IBD launch when it paired groups, 0 when it ran them as uploaded. */
 int fsmc_ctx_set_pairing(fsmc_ctx* ctx, uint32_t mode);
 int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items);
-/* Which kernel family member the last launch ran: n > 0 = the lane-per-pair kernel compiled for n states (69, or
- * the padded members 16, 32, 48, 64, 80), n < 0 = the four-lanes-per-pair kernel with -n states per lane
- * (80 < K <= 256), 0 = the runtime-K kernel (wide models in the modes the four-lane kernel does not have). */
+/* Which kernel the last launch ran: 16 ... 128 = the lane-per-pair kernel compiled for that many states (69, or the
+ * padded members 16, 32, 48, 64, 80, 96, 112, 128); 1048 / 1064 = the four-waves-per-group kernel with 48 / 64 states
+ * per wave (128 < K <= 256). */
 int fsmc_ctx_last_kernel(const fsmc_ctx* ctx, int32_t* member);
 
 /* ---- resident inputs ---- */
