@@ -243,8 +243,9 @@ class Context:
         return float(ms.value)
 
     def phase_cycles(self) -> np.ndarray:
-        out = np.zeros(32, np.uint64)
-        self._check(self._L.fsmc_phase_cycles(self._h, _p(out), 32))
+        out = np.zeros(128, np.uint64)  # kPhaseSlots (fsmc_kernels.h)
+        if self._L.fsmc_phase_cycles(self._h, _p(out), 128) != 0:  # (a library of an earlier round: 32 slots)
+            self._check(self._L.fsmc_phase_cycles(self._h, _p(out), 32))
         return out
 
     def decode_ibd(self, model: "Model", pairs, groups, flags: int = FSMC_WANT_MEAN | FSMC_WANT_MAP) -> np.ndarray:

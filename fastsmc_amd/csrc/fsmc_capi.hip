@@ -628,8 +628,8 @@ int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->dCounters, 4 * sizeof(unsigned));
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->dPhase, 32 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipMemset(ctx->dPhase, 0, 32 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->dPhase, kPhaseSlots * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(ctx->dPhase, 0, kPhaseSlots * sizeof(unsigned long long));
   if (e != hipSuccess) {
     std::string msg = std::string("context set-up failed: ") + hipGetErrorString(e);
     fsmc_ctx_destroy(ctx);
@@ -1344,12 +1344,12 @@ int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms)
 
 int fsmc_phase_cycles(fsmc_ctx* ctx, uint64_t* out, size_t n)
 {
-  if (!ctx || !out || n > 32) {
+  if (!ctx || !out || n > (size_t)kPhaseSlots) {
     return fail(ctx, FSMC_EINVAL, "bad argument");
   }
   FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   FSMC_HIP(ctx, hipMemcpy(out, ctx->dPhase, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  FSMC_HIP(ctx, hipMemset(ctx->dPhase, 0, 32 * sizeof(unsigned long long)));
+  FSMC_HIP(ctx, hipMemset(ctx->dPhase, 0, kPhaseSlots * sizeof(unsigned long long)));
   return FSMC_OK;
 }
 

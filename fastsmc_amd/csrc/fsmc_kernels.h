@@ -300,7 +300,8 @@ template <int N> __device__ __forceinline__ EmisBlk<N> readEmis(const float4* e,
 //   -DFSMC_WAIT_STAMPS    cycles parked in the operand waits of the step functions
 //   -DFSMC_REGION_STAMPS  cycles per code region: FSMC_END(dg, id) charges the time since the previous stamp to region
 //                         id (s_memtime, low 32 bits; the accumulators are flushed once per group)
-constexpr int kDiagRegions = 16;
+constexpr int kDiagRegions = 30; // (the wave-group kernel stamps 30 regions per wave role: fsmc_kernels_w2.h)
+constexpr int kPhaseSlots = 8 + 4 * kDiagRegions; // entries of KParams::phaseCycles
 struct Diag {
   long long waitCycles = 0;
 #if defined(FSMC_REGION_STAMPS)
@@ -1163,6 +1164,35 @@ __device__ __forceinline__ void segment_ages(const int K, const unsigned nAge, c
   }
 }
 
+// The IBD scan's sum over the states below the threshold, k ascending from 0.f (HMM.cpp:1207-1224), over a K-vector in
+// registers; the states it covers are scaled in place on the way.  The walk leaves at the first block of four states
+// beyond the threshold -- one taken branch per site -- and inside the block that holds the threshold the states beyond it
+// add +0.f, which leaves the non-negative sum unchanged.  `nPost` must be a value the compiler cannot prove
+// loop-invariant (launderScalar): the compare of every state was otherwise hoisted out of the site loop as a lane mask in
+// an SGPR pair, all of them spilled -- two v_readlane per state and site in front of every v_cndmask.
+__device__ __forceinline__ unsigned launderScalar(unsigned v)
+{
+  FSMC_GCN_ASM("" : "+s"(v));
+  return v;
+}
+template <int KA, int K, int K4>
+__device__ __forceinline__ void scanBlocks(float (&w)[KA], float& s, const float cq, const unsigned nPost)
+{
+#pragma unroll
+  for (int k4 = 0; k4 < K4; ++k4) {
+    if ((unsigned)(4 * k4) >= nPost) {
+      break;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (4 * k4 + i < K) {
+        w[4 * k4 + i] = w[4 * k4 + i] * cq;
+        s = s + ((unsigned)(4 * k4 + i) < nPost ? w[4 * k4 + i] : 0.f);
+      }
+    }
+  }
+}
+
 // SEQ: sequence mode (DecodingParams::decodingSequence) -- every site step is preceded by an un-normalised
 // half-step across the homozygous stretch since the neighbouring site, and the vectors the posterior is built
 // from are the ones the reference's buffers end up holding (HMM.cpp:767, 922; oracle/hmm_oracle.h):
@@ -1979,18 +2009,8 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             // the states beyond the threshold add +0.f, which leaves the (non-negative) sum unchanged.
             const unsigned nPost = p.stateThr;
             float s = 0.f;
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) {
-              if ((unsigned)(4 * k4) >= nPost) {
-                break;
-              }
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (4 * k4 + i < K) {
-                  w[4 * k4 + i] = w[4 * k4 + i] * cq;
-                  s = s + ((unsigned)(4 * k4 + i) < nPost ? w[4 * k4 + i] : 0.f);
-                }
-              }
+            if constexpr (KT > 0) {
+              scanBlocks<KA, KT, K4A>(w, s, cq, launderScalar(nPost));
             }
             int level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
             if constexpr (DUAL) {
@@ -2073,7 +2093,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
 #if defined(FSMC_REGION_STAMPS)
     if (lane == 0 && p.phaseCycles) {
 #pragma unroll
-      for (int r = 0; r < kDiagRegions; ++r) {
+      for (int r = 0; r < 16; ++r) {
         atomicAdd(&p.phaseCycles[8 + r], (unsigned long long)cycW.acc[r]);
       }
     }

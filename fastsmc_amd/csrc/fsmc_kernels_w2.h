@@ -69,6 +69,75 @@ __device__ __forceinline__ void w2SumBarrier()
 #endif
 }
 
+// A stored K-vector's traffic rides inside the step functions, a piece (one float4 per lane, 1 KiB per wave) at a time
+// between the operand blocks of a wave's first pass, instead of going out as a burst of sixteen between two steps.  One
+// CU moves about 10 B per clock to and from HBM -- a hundred cycles per piece -- and a wave that issues a burst stands at
+// the issue of every piece until the queue has room (region stamps: 12 % of the kernel in the burst behind the combine,
+// 8-10 % around the row stores); spread over a pass the pieces find the queue empty.
+//   out: the row the step STARTS from (beta of site q, final since the end of the step before) goes to HBM piece by piece
+//        just before each block of it is overwritten;
+//   in:  the next site's beta row is requested into the wave's landing zone (LDS-DMA) during the forward step, whose
+//        combine has released the zone.
+// Whether a step moves a row is a compile-time parameter of the step functions (IO): a wave-uniform branch around every
+// piece split the operand blocks' straight-line code and cost hundreds of spilled scalars.  A step of an IO
+// instantiation that has no row to move is given a spare row of the workspace instead.
+struct RowIO {
+  gchar_p base;      // wave-uniform address of this wave's part of the row (lane 0, first state)
+  unsigned laneOff;  // 16 * lane
+  float4* lds;       // in: this wave's landing zone
+};
+__device__ __forceinline__ RowIO noRowIO()
+{
+  const RowIO r = {nullptr, 0u, nullptr};
+  return r;
+}
+// pieces [first, first + n) of the row the step starts from, out of registers
+template <int KH>
+__device__ __forceinline__ void rowOutPieces(const RowIO& io, const float (&v)[KH], const int first, const int n)
+{
+#pragma unroll
+  for (int k4 = first; k4 < first + n; ++k4) {
+    const f32x4 ov = {v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]};
+    __builtin_nontemporal_store(ov, rowSlot(io.base, k4, io.laneOff));
+  }
+}
+// pieces [first, first + n) of the next row, into the landing zone
+__device__ __forceinline__ void rowInPieces(const RowIO& io, const int first, const int n)
+{
+#pragma unroll
+  for (int k4 = first; k4 < first + n; ++k4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(rowSlot(io.base, k4, io.laneOff), &io.lds[k4 * kWave], 16, 0, 2 /* nt */);
+#endif
+  }
+}
+
+// Scalar-cache warm-up in the idle phases.  A pass waits for its operand blocks one at a time (scalar loads return out
+// of order: the only usable wait is lgkmcnt(0)), and a block that misses the 16-KB scalar cache costs an L2 round trip --
+// several hundred cycles while the beta stream keeps L2 busy, against ~130 cycles of arithmetic per block.  A wave works
+// in two of a step's four phases; in a phase it would spend at the barrier it requests one dword of every 64-byte line of
+// the rows its coming passes read (its own part of them), and the phase's barrier waits for them: those passes' blocks then
+// hit.  (The outer waves' first pass is phase 0: nothing to hide behind.  Warming it during the sum of the step before
+// was measured: the requests outlast the sum and the step got longer.)
+template <int KH, int KP, int R0, int R1 = -1, int R2 = -1, int R3 = -1> struct WarmRows {
+  static constexpr int kLines = KH / 16;
+  Touched t0, t1, t2, t3;
+  __device__ __forceinline__ void request(cfloat_p rsw)
+  {
+    touchRow<0, kLines>(t0, rsw, R0 * KP);
+    if constexpr (R1 >= 0) touchRow<0, kLines>(t1, rsw, R1 * KP);
+    if constexpr (R2 >= 0) touchRow<0, kLines>(t2, rsw, R2 * KP);
+    if constexpr (R3 >= 0) touchRow<0, kLines>(t3, rsw, R3 * KP);
+  }
+  __device__ __forceinline__ void landed() const // behind the phase's barrier (it waits for lgkmcnt(0))
+  {
+    heldRow<kLines>(t0);
+    if constexpr (R1 >= 0) heldRow<kLines>(t1);
+    if constexpr (R2 >= 0) heldRow<kLines>(t2);
+    if constexpr (R3 >= 0) heldRow<kLines>(t3);
+  }
+};
+
 struct W2Ctx {
   float* mail;  // [kW2Mail][64] in LDS, shared by the waves of the group
   int lane;
@@ -116,10 +185,11 @@ template <int KH> __device__ __forceinline__ void w2Scale(float (&v)[KH], const 
 
 // One backward step (HMM.cpp:957-1016).  b: this wave's half of beta of site pos+1 on entry, of site pos on exit.
 // rs: the step's RowSet (all 2*KH states); e: this lane's emission values of THIS WAVE's states (LDS).
-template <int KH, int H, bool SCALE = true>
+template <int KH, int H, bool SCALE = true, bool IO = false>
 __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], float (&w)[KH], cfloat_p rs,
-                                             const float4* e, cfloat_p ghostMask)
+                                             const float4* e, cfloat_p ghostMask, Diag& dg, const RowIO& out)
 {
+  FSMC_END(dg, 20); // (region stamps, diagnostic builds: 0-3 work of the phases, 4-7 their barriers, 8 sum, 9 scale)
   constexpr int KP = kW2NW * KH;
   constexpr int kLines = KH / 16; // 64-byte lines of this wave's part of a table row
   static_assert(KH % kWBWide == 0 && KH % 16 == 0 && kLines <= 4, "whole operand blocks and lines");
@@ -172,6 +242,11 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IO && H == kW2NW - 1) {
+        if (!accumulate) {
+          rowOutPieces<KH>(out, b, blk * (BS / 4), BS / 4); // (this block of the row is about to become vec)
+        }
+      }
       float T[BS];
 #pragma unroll
       for (int i = 0; i < BS; i += 2) {
@@ -252,6 +327,11 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IO && H == 0) {
+        if (first) {
+          rowOutPieces<KH>(out, b, blk * (BS / 4), BS / 4); // (this block of the row is about to become vec)
+        }
+      }
       // upper half: beta' of a ghost state is BL, not 0 -- every block is multiplied by its part of the 1/0 mask row
       // (x * 1.0f is exact; ghosts only occur in the upper half)
 #pragma unroll
@@ -302,11 +382,39 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         descending(std::integral_constant<int, kWBWide>{}, tIn, buIn, true);
       }
     }
+    if constexpr (IO && H != 0 && H != kW2NW - 1) {
+      // the inner waves' first pass comes in phase 1: their part of the row goes out in phase 0, which they would
+      // spend at the barrier (the outer waves' first pass IS phase 0: their pieces go between its operand blocks)
+      if (ph == 0) {
+        rowOutPieces<KH>(out, b, 0, KH / 4);
+      }
+    }
+    // idle-phase warm-up (WarmRows): the inner waves sit out phase 0 and then read D, B and Ush, RR in phases 1 and 2;
+    // the outer waves sit out phase 1 and read the rows of their second pass in phase 3
+    WarmRows<KH, KP, kRowD, kRowB, kRowUsh, kRowRR> warmInner;
+    WarmRows<KH, KP, (H == 0 ? kRowUsh : kRowD), (H == 0 ? kRowRR : kRowB)> warmOuter;
+    constexpr bool outer = H == 0 || H == kW2NW - 1;
+    if (!outer && ph == 0) {
+      warmInner.request(rsw);
+    }
+    if (outer && ph == 1) {
+      warmOuter.request(rsw);
+    }
+    FSMC_END(dg, ph);
     w2PhaseBarrier();
+    if (!outer && ph == 0) {
+      warmInner.landed();
+    }
+    if (outer && ph == 1) {
+      warmOuter.landed();
+    }
+    FSMC_END(dg, 4 + ph);
   }
   if constexpr (SCALE) {
     const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
+    FSMC_END(dg, 8);
     w2Scale<KH>(b, w, total);
+    FSMC_END(dg, 9);
   } else { // the un-normalised half-step of sequence mode (HMM.cpp:915-922)
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
@@ -316,10 +424,11 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
 }
 
 // One forward step (HMM.cpp:799-830) + scaling.  a: this wave's half of alpha of site pos-1 on entry, of pos on exit.
-template <int KH, int H, bool SCALE = true>
+template <int KH, int H, bool SCALE = true, bool IO = false>
 __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], float (&w)[KH], cfloat_p rs, cfloat_p cR,
-                                              const float4* e)
+                                              const float4* e, Diag& dg, const RowIO& in)
 {
+  FSMC_END(dg, 21); // (10-13 work of the phases, 14-17 their barriers, 18 sum, 19 scale)
   constexpr int KP = kW2NW * KH;
   constexpr int NBF = KH / kWBF;
   constexpr int kLines = KH / 16;
@@ -487,11 +596,44 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
         finish(cIn);
       }
     }
+    if constexpr (IO) {
+      // the next beta row is requested in the phases a wave would spend at the barrier: the outer waves work in phases
+      // 0 and 3, the inner ones in phases 1 and 2 -- half a row in each idle phase (the combine is a sum pass away)
+      constexpr bool outer = H == 0 || H == kW2NW - 1;
+      if ((outer && ph == 1) || (!outer && ph == 0)) {
+        rowInPieces(in, 0, KH / 8);
+      }
+      if ((outer && ph == 2) || (!outer && ph == 3)) {
+        rowInPieces(in, KH / 8, KH / 4 - KH / 8);
+      }
+    }
+    // idle-phase warm-up (WarmRows): wave 1 reads D, U in phase 1 and B in phase 2, wave 2 D, U, B in phase 2 -- both sit
+    // out phase 0; wave 0 reads B and wave 3 D, U, B in phase 3 -- both sit out phase 1 (the column ratios are one row for
+    // every step: always cached)
+    WarmRows<KH, KP, kRowD, kRowU, kRowB> warmInner;
+    WarmRows<KH, KP, kRowB, (H == 0 ? -1 : kRowD), (H == 0 ? -1 : kRowU)> warmOuter;
+    constexpr bool outerA = H == 0 || H == kW2NW - 1;
+    if (!outerA && ph == 0) {
+      warmInner.request(rsw);
+    }
+    if (outerA && ph == 1) {
+      warmOuter.request(rsw);
+    }
+    FSMC_END(dg, 10 + ph);
     w2PhaseBarrier();
+    if (!outerA && ph == 0) {
+      warmInner.landed();
+    }
+    if (outerA && ph == 1) {
+      warmOuter.landed();
+    }
+    FSMC_END(dg, 14 + ph);
   }
   if constexpr (SCALE) {
     const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
+    FSMC_END(dg, 18);
     w2Scale<KH>(a, w, total);
+    FSMC_END(dg, 19);
   } else { // the un-normalised half-step of sequence mode (HMM.cpp:760-767)
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
@@ -531,6 +673,15 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
   __shared__ float4 coalLds[MODE == kModePerPair ? KP / 4 : 1]; // kModePerPair: expected coalescence times, zero padded
   __shared__ unsigned groupLds;
   __shared__ unsigned char clsLds[kW2NW][kWave]; // kModeSums: observation class of every pair at the current site
+  // Per-lane bookkeeping that lives for a whole group sits in LDS, not in registers: the XOR / AND words of the
+  // current 64 sites of every pair and the table rows of the steps into those sites.  (As registers they were the
+  // values the allocator spilled in the site loops -- reloaded from scratch memory at every site behind a vmcnt(0),
+  // i.e. behind the beta row and the emission rows that had just been requested.)  Lane l of EVERY wave is pair l, so
+  // the four waves compute and write the same values to the same words (a benign race: a wave reads a block's words
+  // only behind its own write, and only in front of the first barrier of a site's step, while no wave can be a
+  // site ahead of another).
+  __shared__ unsigned long long obsLds[2][kWave]; // [XOR | AND][pair]
+  __shared__ int rowLds[2][kWave];                // [64-site block % 2][site % 64]
 
   const int lane = threadIdx.x & (kWave - 1);
   // (wave-uniform BY CONSTRUCTION: as a scalar the compiler branches on it instead of predicating both roles)
@@ -583,26 +734,34 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
     const int to = (int)gw[3];
     const int scanFrom = (int)gw[4];
     const int aEnd = (MODE == kModeIbd) ? (int)gw[5] : to;
-    const bool valid = lane < nPairsInGroup;
-    const unsigned pairIdx = firstPair + (valid ? (unsigned)lane : 0u);
-    const fsmc_pair pr = p.pairs[pairIdx];
-    const unsigned long long* rowA = p.haps + (size_t)pr.hap_a * p.W;
-    const unsigned long long* rowB = p.haps + (size_t)pr.hap_b * p.W;
+    // (recomputed where they are needed -- once per 64 sites, per record, per output row: no registers held for them)
+    auto isValid = [&]() -> bool { return lane < nPairsInGroup; };
+    auto pairIndex = [&]() -> unsigned { return firstPair + (lane < nPairsInGroup ? (unsigned)lane : 0u); };
     const int nA = aEnd - from;
     const int nChunks = (nA + C - 1) / C;
     const bool single = nChunks <= 1;
+    // diagnostic builds only (-DFSMC_REGION_STAMPS): cycles per code region of this wave, flushed per group into
+    // p.phaseCycles[8 + 30 * wave + region]: 0-9 / 10-19 the backward / forward step (see there), 20 / 21 what lies
+    // between two backward steps / in front of a forward step (loop heads, row stores), 22 combine, 23 its sum,
+    // 24 the consumer (25 its requests for the next rows, 26 the scan's sum, 27 decision, 28 its barrier)
+    Diag cycW;
+#if defined(FSMC_REGION_STAMPS)
+    cycW.last = (unsigned)__builtin_readcyclecounter();
+#endif
 
-    int wordIdx = -1;
-    unsigned long long xw = 0, aw = 0;
+    int wordIdx = -1; // (wave-uniform: the 64-site block obsLds holds)
     auto obsClass = [&](const int q) -> int { // 0 het, 1 hom major, 2 hom minor (HMM.cpp:647-652)
       const int wi = q >> 6;
-      if (__builtin_expect(wi != wordIdx, 0)) {
-        const unsigned long long wa = rowA[wi];
-        const unsigned long long wb = rowB[wi];
-        xw = wa ^ wb;
-        aw = wa & wb;
+      if (__builtin_expect(wi != wordIdx, 0)) { // once per 64 sites
+        const fsmc_pair pr = p.pairs[pairIndex()];
+        const unsigned long long wa = p.haps[(size_t)pr.hap_a * p.W + wi];
+        const unsigned long long wb = p.haps[(size_t)pr.hap_b * p.W + wi];
+        obsLds[0][lane] = wa ^ wb;
+        obsLds[1][lane] = wa & wb;
         wordIdx = wi;
+        waitVm0();
       }
+      const unsigned long long xw = obsLds[0][lane], aw = obsLds[1][lane];
       const int bit = q & 63;
       const int x = (int)((xw >> bit) & 1ull);
       const int t = (int)((aw >> bit) & 1ull);
@@ -622,17 +781,25 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
         }
       }
     };
-    int rowBlk = -1;
-    int rowVec = 0;
+    // the 64-site blocks the two slots of rowLds hold (wave-uniform); two slots, so that a block's indices stay readable
+    // while a wave that is ahead loads the next block's
+    int rowBlk0 = -1, rowBlk1 = -1;
     auto stepRowOf = [&](const int site) -> int {
       const int blk = site >> 6;
-      if (__builtin_expect(blk != rowBlk, 0)) {
+      const int slot = blk & 1;
+      if (__builtin_expect(blk != (slot ? rowBlk1 : rowBlk0), 0)) { // once per 64 sites
         const int idx = blk * kWave + lane;
-        rowVec = p.stepRow[idx < p.S ? idx : p.S - 1];
-        rowBlk = blk;
+        rowLds[slot][lane] = p.stepRow[idx < p.S ? idx : p.S - 1];
+        if (slot) {
+          rowBlk1 = blk;
+        } else {
+          rowBlk0 = blk;
+        }
         waitVm0();
+        waitLgkm0();
+        __builtin_amdgcn_wave_barrier();
       }
-      return __builtin_amdgcn_readlane(rowVec, site & (kWave - 1));
+      return __builtin_amdgcn_readfirstlane(rowLds[slot][site & (kWave - 1)]);
     };
     auto rowSetOfRow = [&](const int row) -> cfloat_p { return rowSets + (size_t)row * (kRowSetParts * KP); };
     // emission rows requested one iteration ago have landed (the K4H row stores issued behind them may still be in
@@ -682,18 +849,25 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
         b[k] = (h * KH + k < K) ? 1.0f * c : 0.f;
       }
     };
-    auto betaStepInto = [&](float (&b)[KH], float (&w)[KH], const int q) { // beta of site q -> beta of site q-1
+    // beta of site q -> beta of site q-1.  OUT: the row the step starts from -- beta of site q -- goes to `outRow` piece
+    // by piece during the step (RowIO)
+    auto betaStepInto = [&](float (&b)[KH], float (&w)[KH], const int q, auto moveRow, float4* outRow) {
+      constexpr bool OUT = decltype(moveRow)::value;
       const int c = obsClass(q);
       const cfloat_p rsq = rowSetOfRow(SEQ ? __builtin_amdgcn_readfirstlane(p.rowSiteB[q]) : stepRowOf(q));
       const float4* eq = &emisLds[h][q & 1][c * K4H];
-      FSMC_W2_ROLE(h, (beta_step_w2<KH, H>(cx, b, w, rsq, eq, ghostMask)));
+      const RowIO out = {OUT ? uniformPtr(outRow + halfF4) : (gchar_p) nullptr, laneOff, nullptr};
+      FSMC_W2_ROLE(h, (beta_step_w2<KH, H, true, OUT>(cx, b, w, rsq, eq, ghostMask, cycW, out)));
     };
+    // a spare row of the workspace (checkpoint slot 0 is never a checkpoint): where an OUT step without a row of its
+    // own to store writes
+    float4* const spareRow = ckpt;
     // sequence mode: the un-normalised half-step across the gap (q-1, q), with the homozygous emission row of site q
     // (the fourth row of its ring slot)
     auto betaGapStep = [&](float (&b)[KH], float (&w)[KH], const int q) {
       const cfloat_p rsq = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapB[q]));
       const float4* eq = &emisLds[h][q & 1][3 * K4H];
-      FSMC_W2_ROLE(h, (beta_step_w2<KH, H, false>(cx, b, w, rsq, eq, ghostMask)));
+      FSMC_W2_ROLE(h, (beta_step_w2<KH, H, false>(cx, b, w, rsq, eq, ghostMask, cycW, noRowIO())));
     };
     // the site step out of q = pos+1 (its rows are in the ring), then the half-step towards pos-1 unless pos is the
     // window start; the vector carried from site to site is the STORED one (after the half-step)
@@ -704,7 +878,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
       if (pos > from) {
         stageEmis(pos); // into the slot of site pos + 2, whose steps are over
       }
-      betaStepInto(b, w, q);
+      betaStepInto(b, w, q, std::false_type{}, nullptr);
       if (pos > from) {
         waitVm0();
         __builtin_amdgcn_wave_barrier();
@@ -746,20 +920,42 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
           afterBeta(pos);
         }
       } else {
-        bool stored = afterBeta(to - 1);
+        // Single-chunk windows keep every row of the alpha sweep's range: the row of site q rides out during the step
+        // that starts from it (RowIO; a site beyond the sweep's range writes the spare row), the last one -- beta of the
+        // window's first site -- behind the loop.  Chunked windows keep checkpoints only: a burst once per chunk.
         if (to - 2 >= from) {
           stageEmis(to - 1);
-          stored = false; // (the request is behind the stores: wait for everything once)
         }
-        for (int pos = to - 2; pos >= from; --pos) {
-          const int q = pos + 1;
-          waitEmisRows(stored);
-          __builtin_amdgcn_wave_barrier();
-          if (pos - 1 >= from) {
-            stageEmis(q - 1);
+        if (single) {
+          bool stored = false; // (row stores issued behind the emission-row request of the iteration before)
+          for (int pos = to - 2; pos >= from; --pos) {
+            const int q = pos + 1;
+            waitEmisRows(stored);
+            __builtin_amdgcn_wave_barrier();
+            if (pos - 1 >= from) {
+              stageEmis(q - 1);
+            }
+            betaStepInto(b, w, q, std::true_type{}, q < aEnd ? chunkbuf + (size_t)(q - from) * vecF4 : spareRow);
+            stored = true;
           }
-          betaStepInto(b, w, q);
-          stored = afterBeta(pos);
+          if (from < aEnd) {
+            storeHalf(chunkbuf, b); // beta of the window's first site
+          }
+        } else {
+          bool stored = afterBeta(to - 1);
+          if (to - 2 >= from) {
+            stored = false; // (the request is behind the stores: wait for everything once)
+          }
+          for (int pos = to - 2; pos >= from; --pos) {
+            const int q = pos + 1;
+            waitEmisRows(stored);
+            __builtin_amdgcn_wave_barrier();
+            if (pos - 1 >= from) {
+              stageEmis(q - 1);
+            }
+            betaStepInto(b, w, q, std::false_type{}, nullptr);
+            stored = afterBeta(pos);
+          }
         }
       }
     }
@@ -778,7 +974,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
       }
       if (idx < p.recCap) {
         fsmc_ibd_record r;
-        r.pair = pairIdx;
+        r.pair = pairIndex();
         r.start = s0;
         r.end = s1;
         r.prob = acc;
@@ -796,6 +992,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
         }
         float b[KH];
         int pos;
+        float4* pending = spareRow; // (array mode) where the row in b goes: it rides out during the next step
         if (hi == to) {
           betaInit(b);
           if constexpr (SEQ) {
@@ -805,11 +1002,13 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
               __builtin_amdgcn_wave_barrier();
               betaGapStep(b, w, to - 1);
             }
+            storeHalf(chunkbuf + (size_t)(to - 1 - lo) * vecF4, b);
+          } else {
+            pending = chunkbuf + (size_t)(to - 1 - lo) * vecF4;
           }
-          storeHalf(chunkbuf + (size_t)(to - 1 - lo) * vecF4, b);
           pos = to - 2;
         } else {
-          loadHalf(ckpt + (size_t)(j + 1) * vecF4, b);
+          loadHalf(ckpt + (size_t)(j + 1) * vecF4, b); // (the next chunk's row: not stored here)
           pos = hi - 1;
           if constexpr (SEQ) {
             stageEmis(hi); // the checkpoint is the stored vector of site hi: its rows next
@@ -824,15 +1023,23 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
           if (pos >= lo) {
             stageEmis(pos + 1);
           }
+          // (the row stores of the step before may stay in flight: only the emission rows requested in front of them
+          //  must have landed -- a full wait here parked the wave for a store round trip at every site)
+          // the row a step produces rides out during the step after it (RowIO); the chunk's first row behind the loop
+          bool stored = false;
           for (; pos >= lo; --pos) {
             const int q = pos + 1;
-            waitVm0();
+            waitEmisRows(stored);
             __builtin_amdgcn_wave_barrier();
             if (pos - 1 >= lo) {
               stageEmis(q - 1);
             }
-            betaStepInto(b, w, q);
-            storeHalf(chunkbuf + (size_t)(pos - lo) * vecF4, b);
+            betaStepInto(b, w, q, std::true_type{}, pending);
+            stored = true;
+            pending = chunkbuf + (size_t)(pos - lo) * vecF4;
+          }
+          if (pending != spareRow) {
+            storeHalf(pending, b);
           }
         }
         if (j > 0) {
@@ -871,7 +1078,15 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
           w2Scale<KH>(a, w, total);
         } else {
           const cfloat_p rsp = rowSetOfRow(stepRowOf(pos));
-          FSMC_W2_ROLE(h, (alpha_step_w2<KH, H>(cx, a, w, rsp, tCR, e)));
+          // this site's beta row is requested during the step (RowIO): the combine of the site before has released the
+          // landing zone.  (The chunk's first row was requested in front of the loop: its step requests it once more,
+          // the same bytes.  The sums consumer transposes its tile through the zone and requests the next row itself.)
+          if constexpr (MODE != kModeSums) {
+            const RowIO in = {uniformPtr(chunkbuf + (size_t)(pos - lo) * vecF4 + halfF4), laneOff, &betaLds[h][0]};
+            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H, true, true>(cx, a, w, rsp, tCR, e, cycW, in)));
+          } else {
+            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H>(cx, a, w, rsp, tCR, e, cycW, noRowIO())));
+          }
         }
         if constexpr (SEQ) {
           // what the reference's alpha buffer holds for this site: alpha after the un-normalised half-step across the gap
@@ -881,34 +1096,68 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
             __builtin_amdgcn_wave_barrier();
             const cfloat_p rsg = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapF[pos + 1]));
             const float4* eg = &emisLds[h][(pos + 1) & 1][3 * K4H];
-            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H, false>(cx, a, w, rsg, tCR, eg)));
+            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H, false>(cx, a, w, rsg, tCR, eg, cycW, noRowIO())));
           }
         }
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
         waitVm0();
         __builtin_amdgcn_wave_barrier();
+        // (in blocks of sixteen states, the next block's reads in flight: left to itself the compiler issues all the
+        //  landing-zone reads first -- a third K-vector of registers, and part of alpha went to scratch memory.  What
+        //  orders a block's reads behind the products of the block before is an empty asm statement that takes those
+        //  products as operands and clobbers memory; a scheduling barrier alone does not bind instruction selection)
+        {
+          constexpr int kCB4 = 4; // float4 per block
+          float4 cb[kCB4], nb[kCB4];
 #pragma unroll
-        for (int k4 = 0; k4 < K4H; ++k4) {
-          const float4 bv = betaLds[h][k4 * kWave + lane];
-          const f32x2 a0 = {a[4 * k4], a[4 * k4 + 1]}, a1 = {a[4 * k4 + 2], a[4 * k4 + 3]};
-          const f32x2 b0 = {bv.x, bv.y}, b1 = {bv.z, bv.w};
-          const f32x2 q0 = pmul(a0, b0), q1 = pmul(a1, b1);
-          w[4 * k4] = q0.x;
-          w[4 * k4 + 1] = q0.y;
-          w[4 * k4 + 2] = q1.x;
-          w[4 * k4 + 3] = q1.y;
+          for (int j = 0; j < kCB4; ++j) {
+            cb[j] = betaLds[h][j * kWave + lane];
+          }
+#pragma unroll
+          for (int k4 = 0; k4 < K4H; k4 += kCB4) {
+            if (k4 > 0) {
+              const int k = 4 * (k4 - kCB4);
+              FSMC_GCN_ASM("" ::"v"(w[k]), "v"(w[k + 1]), "v"(w[k + 2]), "v"(w[k + 3]), "v"(w[k + 4]), "v"(w[k + 5]),
+                           "v"(w[k + 6]), "v"(w[k + 7]), "v"(w[k + 8]), "v"(w[k + 9]), "v"(w[k + 10]), "v"(w[k + 11]),
+                           "v"(w[k + 12]), "v"(w[k + 13]), "v"(w[k + 14]), "v"(w[k + 15])
+                           : "memory");
+            }
+            if (k4 + kCB4 < K4H) {
+#pragma unroll
+              for (int j = 0; j < kCB4; ++j) {
+                nb[j] = betaLds[h][(k4 + kCB4 + j) * kWave + lane];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < kCB4; ++j) {
+              const float4 bv = cb[j];
+              const int k = 4 * (k4 + j);
+              const f32x2 a0 = {a[k], a[k + 1]}, a1 = {a[k + 2], a[k + 3]};
+              const f32x2 b0 = {bv.x, bv.y}, b1 = {bv.z, bv.w};
+              const f32x2 q0 = pmul(a0, b0), q1 = pmul(a1, b1);
+              w[k] = q0.x;
+              w[k + 1] = q0.y;
+              w[k + 2] = q1.x;
+              w[k + 3] = q1.y;
+            }
+#pragma unroll
+            for (int j = 0; j < kCB4; ++j) {
+              cb[j] = nb[j];
+            }
+          }
         }
+        FSMC_END(cycW, 22);
         float sumq = 0.f;
         FSMC_W2_ROLE(h, (sumq = w2OrderedTotal<KH, H>(cx, w, kW2RowComb)));
         const float cq = 1.0f / sumq;
-        // every read of the landing zone and of this site's ring slot has returned (the barriers above waited for
-        // lgkmcnt(0)): request the next site's beta row and the rows of site pos + 2
-        if (MODE != kModeSums && pos + 1 < hi) {
-          fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
-        }
+        FSMC_END(cycW, 23);
+        // every read of this site's ring slot has returned (the barriers above waited for lgkmcnt(0)): request the rows of
+        // site pos + 2 (the next site's beta row rides in during its forward step)
         if (pos + 2 < stageEnd) {
           stageEmis(pos + 2);
         }
+        FSMC_END(cycW, 25); // (the requests for the next beta row and emission rows)
 
         if (MODE == kModeSums) {
           // HMM::augmentSumOverPairs (HMM.cpp:1052-1081): per site and state, the batch's posteriors are summed over
@@ -995,9 +1244,9 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
               w2Barrier();
             }
           }
-          if (h == kW2NW - 1 && valid) {
-            if (p.ppMean) p.ppMean[(size_t)pairIdx * p.S + pos] = mean;
-            if (p.ppMap) p.ppMap[(size_t)pairIdx * p.S + pos] = arg;
+          if (h == kW2NW - 1 && isValid()) {
+            if (p.ppMean) p.ppMean[(size_t)pairIndex() * p.S + pos] = mean;
+            if (p.ppMap) p.ppMap[(size_t)pairIndex() * p.S + pos] = arg;
           }
         }
 
@@ -1006,7 +1255,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
 #pragma unroll
           for (int k = 0; k < KH; ++k) {
             if (h * KH + k < K) {
-              out[(size_t)(h * KH + k) * kWave] = valid ? w[k] * cq : 0.f;
+              out[(size_t)(h * KH + k) * kWave] = isValid() ? w[k] * cq : 0.f;
             }
           }
         }
@@ -1018,18 +1267,10 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
             const unsigned nPost = p.stateThr;
             const int nScanWaves = nPost > 3u * KH ? 4 : nPost > 2u * KH ? 3 : nPost > (unsigned)KH ? 2 : 1;
             float s = 0.f;
+            // (this wave's states below the threshold: scanBlocks, fsmc_kernels.h)
             auto partial = [&](float s0) -> float {
-#pragma unroll
-              for (int k4 = 0; k4 < K4H; ++k4) {
-                if ((unsigned)(h * KH + 4 * k4) >= nPost) {
-                  break;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  w[4 * k4 + i] = w[4 * k4 + i] * cq;
-                  s0 = s0 + ((unsigned)(h * KH + 4 * k4 + i) < nPost ? w[4 * k4 + i] : 0.f);
-                }
-              }
+              const unsigned nLocal = nPost - (unsigned)(h * KH) < (unsigned)KH ? nPost - (unsigned)(h * KH) : (unsigned)KH;
+              scanBlocks<KH, KH, K4H>(w, s0, cq, launderScalar(nLocal));
               return s0;
             };
 #pragma unroll
@@ -1049,6 +1290,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
             if (nScanWaves > 1) {
               s = cx.mail[(kW2RowScan + nScanWaves - 1) * kWave + lane];
             }
+            FSMC_END(cycW, 26); // (the scan's sum)
             // the scan's state machine runs in wave 0 (lane = pair)
             int level = 4;
             bool opening = false;
@@ -1056,7 +1298,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
             if (h == 0) {
               level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
               opening = level != 4 && level != cur;
-              closing = valid && cur != 4 && level != cur;
+              closing = isValid() && cur != 4 && level != cur;
             }
             // the other waves hold states the segment ages read: they need the decision, and wave 0 their sums
             const bool upperAges = TRACK && p.ageThr > (unsigned)KH;
@@ -1065,20 +1307,20 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
               if (h == 0) {
                 cx.mail[row * kWave + lane] = __int_as_float(level | (opening ? 8 : 0) | (closing ? 16 : 0));
               } else {
-                // this wave's sums of the sites before are in memory before wave 0 may read them -- but not the requests
-                // for the next site's beta row and emission values issued a moment ago, behind those stores (vector
-                // memory operations retire in order: "at most that many outstanding" means the stores are done)
-                constexpr unsigned nB = (unsigned)K4H, nBE = (unsigned)(K4H + NLE);
-                static_assert(nBE < 64, "vmcnt is a 6-bit counter");
+                // this wave's sums of the sites before are in memory before wave 0 may read them -- but not the request
+                // for the emission values of site pos + 2 issued a moment ago, behind those stores (vector memory
+                // operations retire in order: "at most that many outstanding" means the stores are done)
+                constexpr unsigned nE = (unsigned)NLE;
+                static_assert(nE < 16, "one-digit vmcnt");
                 if (pos + 2 < stageEnd) {
-                  __builtin_amdgcn_s_waitcnt(0x0F70 | (nBE & 15u) | ((nBE >> 4) << 14));
-                } else if (pos + 1 < hi) {
-                  __builtin_amdgcn_s_waitcnt(0x0F70 | (nB & 15u) | ((nB >> 4) << 14));
+                  __builtin_amdgcn_s_waitcnt(0x0F70 | nE);
                 } else {
                   waitVm0();
                 }
               }
+              FSMC_END(cycW, 27); // (decision, or the wait for this wave's sums)
               w2Barrier();
+              FSMC_END(cycW, 28); // (the barrier that hands the decision over)
               if (h != 0) {
                 const int v = __float_as_int(cx.mail[row * kWave + lane]);
                 level = v & 7;
@@ -1133,14 +1375,23 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
                 }
                 w2Barrier();
               }
-              if (h == 0 && valid && cur != 4) {
+              if (h == 0 && isValid() && cur != 4) {
                 emit(segStart, pos);
               }
             }
           }
         }
+        FSMC_END(cycW, 24);
       }
     }
+#if defined(FSMC_REGION_STAMPS)
+    if (lane == 0 && p.phaseCycles) {
+#pragma unroll
+      for (int r = 0; r < kDiagRegions; ++r) {
+        atomicAdd(&p.phaseCycles[8 + kDiagRegions * h + r], (unsigned long long)cycW.acc[r]);
+      }
+    }
+#endif
     // the next group reuses the workspace slot and the mailbox: everything of this one is over in both waves
     waitVm0();
     w2Barrier();
