@@ -58,7 +58,7 @@ def measured_traffic(workload_key: str, beta_stride: int):
     --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction; tools/profile_bench.sh +
     tools/stamp_traffic.py).  PMC collection cannot run inside the timed process, so the figure is the committed
     measurement -- reported only for the workload, stride and library build it was measured on, else null."""
-    d = committed_measurement("r02_traffic.json")
+    d = committed_measurement("r03_traffic.json")
     if not d or d.get("workload_key") != workload_key or d.get("beta_stride") != beta_stride:
         return None
     return float(d["hbm_bytes_per_launch"])
@@ -147,8 +147,10 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("auto", "c2", "c3"), default="auto",
-                    help="auto: c2 at N = 1, c3 (strong scaling of one sharded list) at N > 1")
+    ap.add_argument("--workload", choices=("auto", "c1", "c2", "c3", "c4"), default="auto",
+                    help="auto: c2 at N = 1, c3 (strong scaling of one sharded list) at N > 1; c1: the FASTSMC_EXAMPLE "
+                         "shape (300 haplotypes x 6760 sites, all 44850 pairs); c4: 256 states, 200000-site windows "
+                         "(a 256-haplotype sub-cohort of config 4: 32640 pairs)")
     ap.add_argument("--haps", type=int, default=0, help="haplotypes (default: the workload's)")
     ap.add_argument("--sites", type=int, default=0, help="sites (default: the workload's)")
     ap.add_argument("--pairs", type=int, default=0, help="c3: pairs in the seeded sub-list (default 2^20)")
@@ -189,17 +191,18 @@ def main() -> None:
     from fastsmc_amd.dist import all_pairs_at, gather_ibd_records, sample_pair_ordinals, shard_groups_by_weight
 
     workload = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c3")
-    if workload == "c2":
+    if workload in ("c1", "c2", "c4"):
         # every rank its own cohort (only ever run at N = 1 by the driver; N > 1 here is a weak-scaling rehearsal)
-        n_hap, n_sites = args.haps or 1000, args.sites or 50000
-        pm, bits, haps, _ = build_problem(n_hap, n_sites, args.states, seed=1234 + rank)
+        shape = {"c1": (300, 6760, args.states), "c2": (1000, 50000, args.states), "c4": (256, 200000, 256)}[workload]
+        n_hap, n_sites, n_states = args.haps or shape[0], args.sites or shape[1], shape[2]
+        pm, bits, haps, _ = build_problem(n_hap, n_sites, n_states, seed=1234 + rank)
         pairs = all_pairs(n_hap // 2)
         n_total = int(pairs.shape[0]) * world
         lo, my_pairs = rank * int(pairs.shape[0]), pairs
         desc = (f"synthetic {n_hap} haplotypes x {n_sites} sites, K={pm.K}, all {pairs.shape[0]} pairs per GPU, "
                 f"FastSMC-mode IBD + posterior-mean/MAP ages, no hashing")
-        scaling = "weak"
-        workload_key = f"c2:{n_hap}x{n_sites}:K{pm.K}"
+        scaling = "weak" if world > 1 else "n/a"  # (one GPU: there is nothing to scale)
+        workload_key = f"{workload}:{n_hap}x{n_sites}:K{pm.K}"
     else:
         # ONE problem for all ranks: same seed everywhere, the work list sharded by pair-site weight
         n_hap, n_sites = args.haps or 10000, args.sites or 100000
@@ -217,7 +220,7 @@ def main() -> None:
         desc = (f"synthetic {n_hap} haplotypes x {n_sites} sites, K={pm.K}, a seeded sub-list of {n_total} of the "
                 f"{tot} pairs (enumeration order), sharded over {world} GPU(s) by pair-site weight, FastSMC-mode IBD "
                 f"+ posterior-mean/MAP ages, no hashing")
-        scaling = "strong"
+        scaling = "strong"  # (total work is fixed whatever N: --workload c3 at N = 1 is the first point of the curve)
         workload_key = f"c3:{n_hap}x{n_sites}:K{pm.K}:{n_total}"
     n_mine = int(my_pairs.shape[0])
     groups = capi.whole_sequence_groups(n_mine, pm.S, batch=64)
@@ -301,7 +304,7 @@ def main() -> None:
                          "kernel_ms": 1e3 * k_s, "algorithmic_bytes_per_launch": algo_bytes},
         }
         if scaling == "strong" and world > 1:
-            ref = committed_measurement("r02_c3_n1.json")
+            ref = committed_measurement("r03_c3_n1.json")
             if ref and ref.get("workload_key") == workload_key:
                 out["config"]["n1_pairs_per_s_same_worklist"] = ref["value"]
                 out["config"]["speedup_vs_n1"] = value / ref["value"]

@@ -38,11 +38,12 @@ def hip_sources() -> list[str]:
 
 
 def hip_source_hash() -> str:
-    """Hash of the HIP library's sources: profiles/*_traffic.json carry it so that a measurement of another build
-    is not reported for this one (bench.py)."""
+    """Hash of the HIP library's sources -- every .hip / .h under csrc/, the public header -- and of the compiler flags:
+    profiles/*_traffic.json carry it so that a measurement of another build is not reported for this one (bench.py)."""
     import hashlib
 
     h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())  # (a build with other flags is another library)
     for s in hip_sources():
         h.update(os.path.basename(s).encode())
         h.update(open(s, "rb").read())
@@ -85,7 +86,7 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
 
 HOST_DIR = os.path.join(CSRC, "host")
 HOST_SOURCES = ["decoding_quantities.cpp", "decoding_params.cpp", "data.cpp", "hmm.cpp", "hashing.cpp", "drivers.cpp",
-                "pybind_module.cpp"]
+                "pybind_module.cpp", "pybind_containers.cpp"]
 
 
 def host_module_path() -> str:

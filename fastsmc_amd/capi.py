@@ -31,8 +31,8 @@ SYMBOLS = [
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
     "fsmc_decode_ibd",
-    "fsmc_decode_posteriors", "fsmc_decode_per_pair", "fsmc_decode_sums",
-    "fsmc_identify",
+    "fsmc_decode_posteriors", "fsmc_decode_per_pair", "fsmc_decode_sums", "fsmc_decode_sums_batches",
+    "fsmc_identify", "fsmc_identify_fetch",
 ]
 
 PAIR_DTYPE = np.dtype([("hap_a", "<u4"), ("hap_b", "<u4")])
@@ -109,8 +109,10 @@ def load():
         L.fsmc_decode_posteriors.argtypes = [vp, vp, vp, sz]
         L.fsmc_decode_per_pair.argtypes = [vp, vp, vp, vp, vp]
         L.fsmc_decode_sums.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.fsmc_decode_sums_batches.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
         L.fsmc_identify.argtypes = [vp, vp, u32, u32, vp, C.POINTER(_JobWindow), vp, u32, i32, C.c_float, C.c_float, vp,
                                     sz, C.POINTER(sz)]
+        L.fsmc_identify_fetch.argtypes = [vp, vp, sz, C.POINTER(sz)]
         _lib = L
     return _lib
 
@@ -272,8 +274,11 @@ class Context:
             n = C.c_size_t(0)
             rc = self._L.fsmc_identify(self._h, _p(w), w.shape[0], w.shape[1], _p(ids), C.byref(jw), _p(gen), gen.size,
                                        gap, skip, min_m, _p(out), cap, C.byref(n))
-            if rc == -6:  # FSMC_EOVERFLOW: n holds the count
+            if rc == -6:  # FSMC_EOVERFLOW: n holds the count, the finished list waits on the device
                 cap = int(n.value)
+                out = np.zeros(cap, CANDIDATE_DTYPE)
+                if self._L.fsmc_identify_fetch(self._h, _p(out), cap, C.byref(n)) == 0:
+                    return out[:n.value]
                 continue
             self._check(rc)
             return out[:n.value]
@@ -286,9 +291,11 @@ class Context:
         self._check(self._L.fsmc_decode_per_pair(self._h, model._h, _p(et), _p(mean), _p(mp)))
         return mean, mp
 
-    def decode_sums(self, model: "Model", major_minor: bool = False, sums: bool = True, into=None):
+    def decode_sums(self, model: "Model", major_minor: bool = False, sums: bool = True, into=None, batch_first_group=None):
         """augmentSumOverPairs for the resident work list: arrays [S][K] (sum, and 00/01/11 when asked).  ``into`` =
-        (sum, [s00, s01, s11]) of an earlier call continues that accumulation (sumOverPairs += ..., HMM.cpp:1073)."""
+        (sum, [s00, s01, s11]) of an earlier call continues that accumulation (sumOverPairs += ..., HMM.cpp:1073).
+        ``batch_first_group`` (n_batches + 1 entries): the reference batches, as runs of consecutive groups, when a
+        batch holds more than 64 pairs (fsmc_decode_sums_batches)."""
         shape = (model.S, model.K)
         if into is not None:
             s, mm = into
@@ -296,7 +303,12 @@ class Context:
         else:
             s = np.zeros(shape, np.float32) if sums else None
             mm = [np.zeros(shape, np.float32) for _ in range(3)] if major_minor else [None, None, None]
-        self._check(self._L.fsmc_decode_sums(self._h, model._h, _p(s), _p(mm[0]), _p(mm[1]), _p(mm[2])))
+        if batch_first_group is not None:
+            bf = np.ascontiguousarray(batch_first_group, np.uint32)
+            self._check(self._L.fsmc_decode_sums_batches(self._h, model._h, _p(bf), bf.size - 1, _p(s), _p(mm[0]),
+                                                         _p(mm[1]), _p(mm[2])))
+        else:
+            self._check(self._L.fsmc_decode_sums(self._h, model._h, _p(s), _p(mm[0]), _p(mm[1]), _p(mm[2])))
         return s, mm
 
     def decode_posteriors(self, model: "Model") -> list[np.ndarray]:

@@ -94,7 +94,9 @@ struct fsmc_ctx {
   // work list and budget, longest window first.
   struct IbdQueues {
     uint64_t serial = 0;  // work list they were built from
-    uint64_t maxLen = 0;  // pairing budget they were built with
+    uint64_t maxLen = 0;  // pairing budgets they were built with: beside a second kernel ...
+    uint64_t maxLenAlone = 0; // ... and with the whole workspace (they move with the model member, the beta stride and
+                              // the workspace limit, not always together)
     uint32_t pairing = 0;
     bool valid = false;
     bool dual = false;    // items/unions in use: two half-groups per wave
@@ -110,6 +112,9 @@ struct fsmc_ctx {
   hipStream_t side = nullptr;   // the one-group-per-wave kernel of a paired decode runs here, beside the paired kernel
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   DevBuf wsSide;
+
+  DevBuf idStash;       // fsmc_identify on overflow: the complete, ordered candidate list, kept for fsmc_identify_fetch
+  size_t idStashCount = 0;
 
   const fsmc_model* ibdModel = nullptr;
   uint32_t ibdFlags = 0;
@@ -136,8 +141,8 @@ namespace
 
 // Two copies of the HIP runtime in one process (e.g. this library linked against /opt/rocm and a PyTorch wheel that
 // bundles its own libamdhip64, loaded in that order) share the device but not their state: kernels built for one
-// wave per SIMD then fail to launch with an opaque "unknown error" from the occupancy query.  Look at the mapped
-// files and say so instead.  Returns the paths of the distinct runtimes found.
+// wave per SIMD then fail to launch with an opaque "unknown error" from the occupancy query.  When that query fails,
+// fsmc_ctx_create looks at the mapped files and says so.  Returns the paths of the distinct runtimes found.
 std::vector<std::string> mappedHipRuntimes()
 {
   std::vector<std::string> found;
@@ -472,8 +477,8 @@ int checkReady(fsmc_ctx* ctx, const fsmc_model* m)
       return fail(ctx, FSMC_EINVAL, "group window exceeds the number of sites");
     }
   }
-  if (m->K > kMaxGenericK) {
-    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxGenericK) + " states");
+  if (m->K > kMaxStates) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxStates) + " states");
   }
   return FSMC_OK;
 }
@@ -573,18 +578,6 @@ int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
     return fail(nullptr, FSMC_EINVAL, "out is null");
   }
   *out = nullptr;
-  {
-    const std::vector<std::string> rts = mappedHipRuntimes();
-    if (rts.size() > 1) {
-      std::string msg = "two HIP runtimes are loaded in this process (";
-      for (size_t i = 0; i < rts.size(); ++i) {
-        msg += (i ? ", " : "") + rts[i];
-      }
-      msg += "): load one libamdhip64 only -- e.g. import torch before this library so that both resolve to the "
-             "copy torch bundles, or link both against the same ROCm";
-      return fail(nullptr, FSMC_ENODEVICE, msg);
-    }
-  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -635,6 +628,31 @@ int fsmc_ctx_create(int device_id, void* stream, fsmc_ctx** out)
     fsmc_ctx_destroy(ctx);
     return fail(nullptr, FSMC_EHIP, msg);
   }
+  // Two copies of the HIP runtime in the process (mappedHipRuntimes) are a DIAGNOSIS, not a gate: an embedding process
+  // may map a second copy and still launch fine.  So try what breaks in that case -- the occupancy query of a kernel
+  // built for one wave per SIMD -- and name the cause only if it does.
+  {
+    int blocks = 0;
+    const hipError_t pe = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+      &blocks, decode_kernel<128, kModeIbd, true, false, false>, kWave, 0);
+    if (pe != hipSuccess) {
+      (void)hipGetLastError();
+      const std::vector<std::string> rts = mappedHipRuntimes();
+      std::string msg = std::string("kernels of this library cannot be launched (") + hipGetErrorString(pe) + ")";
+      int code = FSMC_EHIP;
+      if (rts.size() > 1) {
+        code = FSMC_ERUNTIME;
+        msg += ": two HIP runtimes are loaded in this process (";
+        for (size_t i = 0; i < rts.size(); ++i) {
+          msg += (i ? ", " : "") + rts[i];
+        }
+        msg += "): load one libamdhip64 only -- e.g. import torch before this library so that both resolve to the "
+               "copy torch bundles, or link both against the same ROCm";
+      }
+      fsmc_ctx_destroy(ctx);
+      return fail(nullptr, code, msg);
+    }
+  }
   *out = ctx;
   return FSMC_OK;
 }
@@ -655,6 +673,7 @@ void fsmc_ctx_destroy(fsmc_ctx* ctx)
   if (ctx->dRest) (void)hipFree(ctx->dRest);
   if (ctx->dCounters) (void)hipFree(ctx->dCounters);
   if (ctx->dPhase) (void)hipFree(ctx->dPhase);
+  if (ctx->idStash.p) (void)hipFree(ctx->idStash.p);
   if (ctx->ws.p) (void)hipFree(ctx->ws.p);
   if (ctx->recs.p) (void)hipFree(ctx->recs.p);
   if (ctx->aux.p) (void)hipFree(ctx->aux.p);
@@ -745,8 +764,8 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   if (d->K < 2 || d->S < 1 || d->n_rows < 1) {
     return fail(ctx, FSMC_EINVAL, "need K >= 2, S >= 1, n_rows >= 1");
   }
-  if (d->K > kMaxGenericK) {
-    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxGenericK) + " states");
+  if (d->K > kMaxStates) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxStates) + " states");
   }
   if (!d->pi || !d->col_ratios || !d->exp_times || !d->D || !d->B || !d->U || !d->RR || !d->step_row || !d->e1 ||
       !d->e0m1 || !d->e2m0) {
@@ -1117,7 +1136,8 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     maxLenAlone = 2 * rowsAvail > 16 ? std::min<size_t>((2 * rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
   }
   fsmc_ctx::IbdQueues& q = ctx->q;
-  if (!q.valid || q.serial != ctx->worklistSerial || q.maxLen != maxLen || q.pairing != ctx->pairing) {
+  if (!q.valid || q.serial != ctx->worklistSerial || q.maxLen != maxLen || q.maxLenAlone != maxLenAlone ||
+      q.pairing != ctx->pairing) {
     q.valid = false;
     q.items.clear();
     q.unions.clear();
@@ -1151,6 +1171,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     }
     q.serial = ctx->worklistSerial;
     q.maxLen = maxLen;
+    q.maxLenAlone = maxLenAlone;
     q.pairing = ctx->pairing;
     q.valid = true;
   }
@@ -1297,7 +1318,34 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
   FSMC_HIP(ctx, hipMemcpyAsync(&count, b.p[6], sizeof(count), hipMemcpyDeviceToHost, ctx->stream));
   FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *n_out = count;
+  ctx->idStashCount = 0;
   if (count > cap) {
+    // The caller's buffer is too small -- the normal case of a first call, nobody knows the count beforehand.  Only the
+    // last pass depends on the buffer: run it again into one of the right size (the duplicate and complexity bits are
+    // still there), order the records and keep them on the device for fsmc_identify_fetch, so that the caller does not
+    // pay the uploads and the two other passes twice.
+    void* full = nullptr;
+    hipError_t e = hipMalloc(&full, (size_t)count * sizeof(fsmc_candidate));
+    if (e == hipSuccess) {
+      p.out = (fsmc_candidate*)full;
+      p.cap = count;
+      e = hipMemsetAsync(b.p[6], 0, bytes[6], ctx->stream);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(id_match_kernel, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess && ensure(ctx, ctx->idStash, (size_t)count * sizeof(fsmc_candidate)) == FSMC_OK) {
+        e = idSortCandidates(ctx->stream, (const fsmc_candidate*)full, (fsmc_candidate*)ctx->idStash.p, count, n_haps,
+                             n_words);
+        if (e == hipSuccess) {
+          e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess) {
+          ctx->idStashCount = count;
+        }
+      }
+      (void)hipFree(full);
+    }
     return fail(ctx, FSMC_EOVERFLOW, "fsmc_identify: candidate buffer too small");
   }
   if (count) {
@@ -1317,6 +1365,27 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
       return fail(ctx, FSMC_EHIP, std::string("fsmc_identify: ordering the candidates failed: ") + hipGetErrorString(e));
     }
   }
+  return FSMC_OK;
+}
+
+int fsmc_identify_fetch(fsmc_ctx* ctx, fsmc_candidate* out, size_t cap, size_t* n_out)
+{
+  if (!ctx || !n_out) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify_fetch: null argument");
+  }
+  *n_out = ctx->idStashCount;
+  if (ctx->idStashCount == 0) {
+    return fail(ctx, FSMC_ESTATE, "fsmc_identify_fetch: no candidate list is kept (it follows an fsmc_identify that "
+                                  "returned FSMC_EOVERFLOW)");
+  }
+  if (cap < ctx->idStashCount || !out) {
+    return fail(ctx, FSMC_EOVERFLOW, "fsmc_identify_fetch: candidate buffer too small");
+  }
+  FSMC_HIP(ctx, hipSetDevice(ctx->device));
+  FSMC_HIP(ctx, hipMemcpy(out, ctx->idStash.p, ctx->idStashCount * sizeof(fsmc_candidate), hipMemcpyDeviceToHost));
+  ctx->idStashCount = 0;
+  (void)hipFree(ctx->idStash.p);
+  ctx->idStash = DevBuf{};
   return FSMC_OK;
 }
 
@@ -1500,9 +1569,28 @@ int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model* m, const float* exp_co
 
 int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sums00, float* sums01, float* sums11)
 {
+  return fsmc_decode_sums_batches(ctx, m, nullptr, 0, sums, sums00, sums01, sums11);
+}
+
+int fsmc_decode_sums_batches(fsmc_ctx* ctx, const fsmc_model* m, const uint32_t* batch_first_group, size_t n_batches,
+                             float* sums, float* sums00, float* sums01, float* sums11)
+{
   int rc = checkReady(ctx, m);
   if (rc != FSMC_OK) {
     return rc;
+  }
+  if (batch_first_group) {
+    // batch b = groups batch_first_group[b] .. batch_first_group[b + 1] - 1: a partition of the group list, in order
+    if (n_batches == 0 || batch_first_group[0] != 0 || batch_first_group[n_batches] != ctx->nGroups) {
+      return fail(ctx, FSMC_EINVAL, "batches must partition the group list");
+    }
+    for (size_t bI = 0; bI < n_batches; ++bI) {
+      if (batch_first_group[bI + 1] <= batch_first_group[bI]) {
+        return fail(ctx, FSMC_EINVAL, "a batch holds at least one group and batches are in group order");
+      }
+    }
+  } else {
+    n_batches = ctx->nGroups; // every group is a batch of its own
   }
   const bool mm = sums00 || sums01 || sums11;
   if (!sums && !mm) {
@@ -1523,14 +1611,15 @@ int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sum
   if (rc != FSMC_OK) {
     return rc;
   }
-  // One launch decodes up to `slots` groups (one per wave; slots = resident waves, fewer if the planes would not fit)
-  // and leaves each group's batch sums in its own plane; add_planes_in_order_kernel then adds the planes to the
-  // accumulator in group order.  The accumulator starts from the caller's arrays, so that several calls (flushes)
+  // One launch decodes up to `slots` batches (one per wave; slots = resident waves, fewer if the planes would not fit)
+  // and leaves each batch's sums in its own plane (the groups of a batch of more than 64 pairs in turn, each continuing
+  // the running sums of the one before); add_planes_in_order_kernel then adds the planes to the accumulator in batch
+  // order.  The accumulator starts from the caller's arrays, so that several calls (flushes)
   // continue the same sequential sum.
   const size_t plane = (size_t)m->S * m->K;
   const int nP = mm ? 4 : 1; // planes per group: the sum, or the sum and its 00 / 01 / 11 split
   const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.25 * (double)ctx->hbmBytes);
-  size_t slots = (size_t)plan.slots;
+  size_t slots = std::min<size_t>((size_t)plan.slots, n_batches);
   slots = std::max<size_t>(1, std::min<size_t>(slots, limit / (4 * plane * sizeof(float))));
   if (const char* cap = std::getenv("FSMC_DIAG_SUMS_SLOTS")) { // tests: force many launches on a small problem
     const long v = std::atol(cap);
@@ -1555,8 +1644,17 @@ int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sum
   p.sums = (float*)ctx->out.p;
   p.sumsPlane = plane;
   (void)nP;
-  for (size_t base = 0; base < ctx->nGroups; base += slots) {
-    const size_t n = std::min(slots, ctx->nGroups - base);
+  if (batch_first_group) {
+    rc = ensure(ctx, ctx->aux, (n_batches + 1) * sizeof(uint32_t));
+    if (rc != FSMC_OK) {
+      return rc;
+    }
+    FSMC_HIP(ctx, hipMemcpyAsync(ctx->aux.p, batch_first_group, (n_batches + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 ctx->stream));
+    p.batchFirst = (const unsigned*)ctx->aux.p;
+  }
+  for (size_t base = 0; base < n_batches; base += slots) {
+    const size_t n = std::min(slots, n_batches - base);
     p.groupBase = (int)base;
     rc = launch(ctx, fn, p, (int)n, blockThreads(kModeSums, m));
     if (rc != FSMC_OK) {

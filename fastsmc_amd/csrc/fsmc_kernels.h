@@ -37,8 +37,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMaxGenericK = 256; // upper bound on K for the generic (runtime-K) steps -- KT = 0, no longer instantiated
-                                  // in the library: kept for the -DFSMC_NO_PK comparison builds
+constexpr int kMaxStates = 256; // the widest model a kernel family member decodes (fsmc_instances.h)
 
 enum Mode : int { kModeIbd = 0, kModeDump = 1, kModePerPair = 2, kModeSums = 3 };
 
@@ -48,7 +47,7 @@ struct KParams {
   int S;       // sites
   int W;       // 64-bit words per haplotype row
   int nGroups;
-  int groupBase; // kModeSums: this launch decodes groups groupBase .. groupBase + gridDim.x - 1, one per wave;
+  int groupBase; // kModeSums: this launch decodes batches groupBase .. groupBase + gridDim.x - 1, one per wave;
                  // other modes: which of `counters` is this launch's queue head
   int chunk;   // sites per chunk (C)
   int chunkRows; // rows of the chunk buffer: C, or (C+1)/2 with beta stride 2
@@ -86,6 +85,7 @@ struct KParams {
   unsigned long long* phaseCycles; // diagnostic builds (-DFSMC_PHASE_STAMPS): [0] pass B, [1] rebuild, [2] alpha sweep, [3] groups
   float* sums;                // kModeSums: one plane [S][K] (x4 with the 00/01/11 sums) per wave of the launch
   size_t sumsPlane;           // floats per plane per slot
+  const unsigned* batchFirst; // kModeSums: [nBatches + 1] first group of every batch (null: every group is a batch)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -105,20 +105,6 @@ struct KParams {
 #define FSMC_GCN_ASM(...) ((void)0)
 #endif
 
-// (the forms without an offset serve the runtime-K steps, whose block loops are real loops with spilled registers all
-//  around: they wait inside the same asm statement, so that nothing can touch a destination in flight)
-__device__ __forceinline__ f32x4 sload4(cfloat_p p)
-{
-  f32x4 v = {};
-  FSMC_GCN_ASM("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-  return v;
-}
-__device__ __forceinline__ f32x8 sload8(cfloat_p p)
-{
-  f32x8 v = {};
-  FSMC_GCN_ASM("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-  return v;
-}
 // The same loads with the block's byte offset as an instruction immediate (compile-time K: the unrolled block
 // index is a constant by the time the instruction is selected) -- no scalar address arithmetic per load.
 __device__ __forceinline__ f32x4 sload4(cfloat_p p, const int byteOff)
@@ -165,12 +151,6 @@ __device__ __forceinline__ void holdTouched(Touched& a)
   FSMC_GCN_ASM("" : "+s"(a.r[0]), "+s"(a.r[1]), "+s"(a.r[2]), "+s"(a.r[3]));
 }
 #define FSMC_SWAIT_INSN "s_waitcnt lgkmcnt(0)"
-__device__ __forceinline__ f32x16 sload16(cfloat_p p)
-{
-  f32x16 v = {};
-  FSMC_GCN_ASM("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-  return v;
-}
 __device__ __forceinline__ void swait(f32x8& a, f32x8& b)
 {
   FSMC_GCN_ASM(FSMC_SWAIT_INSN : "+s"(a), "+s"(b));
@@ -187,17 +167,14 @@ __device__ __forceinline__ void swait(f32x8& a, f32x8& b, f32x8& c, f32x8& d)
 template <int N> struct SV;
 template <> struct SV<4> {
   typedef f32x4 T;
-  static __device__ __forceinline__ T load(cfloat_p p) { return sload4(p); }
   static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState) { return sload4(p, firstState * 4); }
 };
 template <> struct SV<8> {
   typedef f32x8 T;
-  static __device__ __forceinline__ T load(cfloat_p p) { return sload8(p); }
   static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState) { return sload8(p, firstState * 4); }
 };
 template <> struct SV<16> {
   typedef f32x16 T;
-  static __device__ __forceinline__ T load(cfloat_p p) { return sload16(p); }
   static __device__ __forceinline__ T loadAt(cfloat_p p, const int firstState)
   {
     f32x16 v = {};
@@ -320,183 +297,10 @@ struct Diag {
 #define FSMC_END(dg, id) ((void)0)
 #endif
 
-// One step of the backward recursion for one pair (HMM.cpp:957-1016, NO_SSE association).
-// b: beta of site pos+1 (scaled) on entry, beta of site pos (scaled) on exit.  w: scratch.
-// e: this lane's emission row for site pos+1 (LDS).  Dr/Br/Ur/RRr: wave-uniform table rows.
-// SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:915-922).
-template <int KT, int KA, bool SCALE = true>
-__device__ __forceinline__ void beta_step_1(const int K, float (&b)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                            cfloat_p Ur, cfloat_p RRr, const float4* e, Diag& dg)
-{
-  typedef typename SV<kKB>::T SVec;
-  const int NB = (K + kKB - 1) / kKB;
-  // descending: vec[k] = beta[k]*e[k];  BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1]  (BU[K-1] = 0)
-  SVec u = SV<kKB>::load(Ur + (NB - 1) * kKB);
-  SVec rr = SV<kKB>::load(RRr + (NB - 1) * kKB);
-  EmisBlk<kKB> em = readEmis<kKB>(e, NB - 1);
-  SVec d, bt; // operands of the ascending pass; its first block is requested during the last descending block
-  // With a runtime K these loops are real loops: a register holding a scalar load still in flight must not be
-  // copied across the back-edge, so the generic instantiation loads and waits per block instead of prefetching.
-#pragma unroll
-  for (int blk = NB - 1; blk >= 0; --blk) {
-    if (KT == 0 && blk < NB - 1) {
-      u = SV<kKB>::load(Ur + blk * kKB);
-      rr = SV<kKB>::load(RRr + blk * kKB);
-      em = readEmis<kKB>(e, blk);
-    }
-    FSMC_SWAIT(dg.waitCycles, u, rr);
-    SVec nu = u, nrr = rr;
-    EmisBlk<kKB> nem = em;
-    if (KT > 0) {
-      if (blk > 0) {
-        nu = SV<kKB>::load(Ur + (blk - 1) * kKB);
-        nrr = SV<kKB>::load(RRr + (blk - 1) * kKB);
-        nem = readEmis<kKB>(e, blk - 1);
-      } else {
-        d = SV<kKB>::load(Dr);
-        bt = SV<kKB>::load(Br);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = kKB - 1; i >= 0; --i) {
-      const int k = blk * kKB + i;
-      if (k < K) {
-        b[k] = b[k] * em.at(i);
-        if (k == K - 1) {
-          w[k] = 0.f;
-        } else {
-          w[k] = u[i] * b[k + 1] + rr[i] * w[k + 1];
-        }
-      }
-    }
-    u = nu;
-    rr = nrr;
-    em = nem;
-  }
-  // ascending: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  beta'[k] = (BL[k] + D[k]*vec[k]) + BU[k]
-  float BL = 0.f;
-  float sum = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
-    if (KT == 0) {
-      d = SV<kKB>::load(Dr + blk * kKB);
-      bt = SV<kKB>::load(Br + blk * kKB);
-    }
-    FSMC_SWAIT(dg.waitCycles, d, bt);
-    SVec nd = d, nbt = bt;
-    if (KT > 0 && blk + 1 < NB) {
-      nd = SV<kKB>::load(Dr + (blk + 1) * kKB);
-      nbt = SV<kKB>::load(Br + (blk + 1) * kKB);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < kKB; ++i) {
-      const int k = blk * kKB + i;
-      if (k < K) {
-        w[k] = (BL + d[i] * b[k]) + w[k];
-        sum = sum + w[k];
-        if (k < K - 1) {
-          BL = BL + bt[i] * b[k];
-        }
-      }
-    }
-    d = nd;
-    bt = nbt;
-  }
-  if constexpr (SCALE) {
-    const float c = 1.0f / sum;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      b[k] = w[k] * c;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      b[k] = w[k];
-    }
-  }
-}
-
-// One step of the forward recursion (HMM.cpp:799-830) followed by the per-site scaling
-// (HmmUtils.cpp:102-151).  a: alpha of site pos-1 on entry, of site pos on exit.
-// SCALE = false: the un-normalised half-step of sequence mode (HMM.cpp:760-767).
-template <int KT, int KA, bool SCALE = true>
-__device__ __forceinline__ void alpha_step_1(const int K, float (&a)[KA], float (&w)[KA], cfloat_p Dr, cfloat_p Br,
-                                             cfloat_p Ur, cfloat_p cR, const float4* e, Diag& dg)
-{
-  typedef typename SV<kKBF>::T SVec;
-  const int NB = (K + kKBF - 1) / kKBF;
-  // first operand block requested before the operand-free suffix-sum pass
-  SVec d = SV<kKBF>::load(Dr), bt = SV<kKBF>::load(Br), u = SV<kKBF>::load(Ur), c4 = SV<kKBF>::load(cR);
-  EmisBlk<kKBF> em = readEmis<kKBF>(e, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  // alphaC[k] = sum_{i>=k} alpha[i], accumulated from the top (HMM.cpp:799-814)
-  w[K - 1] = a[K - 1];
-#pragma unroll
-  for (int k = K - 2; k >= 0; --k) {
-    w[k] = w[k + 1] + a[k];
-  }
-  float AU = 0.f;
-  float sum = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
-    if (KT == 0 && blk > 0) {
-      d = SV<kKBF>::load(Dr + blk * kKBF);
-      bt = SV<kKBF>::load(Br + blk * kKBF);
-      u = SV<kKBF>::load(Ur + blk * kKBF);
-      c4 = SV<kKBF>::load(cR + blk * kKBF);
-      em = readEmis<kKBF>(e, blk);
-    }
-    FSMC_SWAIT(dg.waitCycles, d, bt, u, c4);
-    SVec nd = d, nbt = bt, nu = u, nc = c4;
-    EmisBlk<kKBF> nem = em;
-    if (KT > 0 && blk + 1 < NB) {
-      nd = SV<kKBF>::load(Dr + (blk + 1) * kKBF);
-      nbt = SV<kKBF>::load(Br + (blk + 1) * kKBF);
-      nu = SV<kKBF>::load(Ur + (blk + 1) * kKBF);
-      nc = SV<kKBF>::load(cR + (blk + 1) * kKBF);
-      nem = readEmis<kKBF>(e, blk + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < kKBF; ++i) {
-      const int k = blk * kKBF + i;
-      if (k < K) {
-        float term = AU + d[i] * a[k];
-        if (k < K - 1) {
-          term = term + bt[i] * w[k + 1];
-        }
-        w[k] = em.at(i) * term;
-        sum = sum + w[k];
-        if (k < K - 1) {
-          AU = u[i] * a[k] + c4[i] * AU; // AU of state k+1
-        }
-      }
-    }
-    d = nd;
-    bt = nbt;
-    u = nu;
-    c4 = nc;
-    em = nem;
-  }
-  if constexpr (SCALE) {
-    const float c = 1.0f / sum;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      a[k] = w[k] * c;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      a[k] = w[k];
-    }
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// Packed variants of the two steps for a compile-time K.  gfx950 multiplies / adds two fp32 values per lane in one
+// The two steps, K a compile-time parameter (the kernel family, fsmc_instances.h).  One step of the backward recursion
+// for one pair is HMM.cpp:957-1016 (NO_SSE association), of the forward recursion HMM.cpp:799-830 followed by the
+// per-site scaling (HmmUtils.cpp:102-151).  gfx950 multiplies / adds two fp32 values per lane in one
 // VALU instruction (v_pk_mul_f32, v_pk_add_f32) when both sit in an aligned register pair.  Every operation of a
 // step that is not part of a first-order recurrence is done for states (k, k+1) at once; the recurrences (BU, BL,
 // AU, the suffix sum, the scaling sum) stay scalar and sequential.  Each value is produced by the same IEEE
@@ -957,21 +761,13 @@ __device__ __forceinline__ void alpha_step_pk(float (&a)[KA], float (&w)[KA], cf
 
 
 
-#if defined(FSMC_NO_PK)
-constexpr bool kPacked = false;
-#else
-constexpr bool kPacked = true;
-#endif
-
-// The tables as the kernel addresses them: `row` selects the key.  Packed steps read the RowSet copy, the generic
-// (runtime-K) steps the four separate tables.
+// The tables as the kernel addresses them: `row` selects the key of the RowSet copy.
 struct Tables {
-  cfloat_p D, B, U, RR, rowSets, cR, ghostMask;
-  int KP;
+  cfloat_p rowSets, cR, ghostMask;
 };
 
 // compile-time K that is a whole number of operand blocks = a padded family member (K <= KT real states)
-template <int KT> constexpr bool kGhost = KT > 0 && KT % kKPad == 0;
+template <int KT> constexpr bool kGhost = KT % kKPad == 0;
 
 template <int KT> __device__ __forceinline__ cfloat_p rowSetOf(const Tables& t, const int row)
 {
@@ -983,26 +779,16 @@ template <int KT, int KA, bool SCALE = true, bool SY = false>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], const Tables& t, const int row,
                                           const float4* e, Diag& dg)
 {
-  if constexpr (KT > 0 && kPacked) {
-    beta_step_pk<KT, KA, SCALE, kGhost<KT>, SY>(b, w, rowSetOf<KT>(t, row), e, t.ghostMask, dg);
-  } else {
-    const size_t o = (size_t)row * t.KP;
-    beta_step_1<KT, KA, SCALE>(K, b, w, t.D + o, t.B + o, t.U + o, t.RR + o, e, dg);
-    waitLgkm0(); // (runtime-K loops: closes the paths on which a block loop would run zero times)
-  }
+  (void)K;
+  beta_step_pk<KT, KA, SCALE, kGhost<KT>, SY>(b, w, rowSetOf<KT>(t, row), e, t.ghostMask, dg);
 }
 
 template <int KT, int KA, bool SCALE = true, bool SY = false>
 __device__ __forceinline__ void alpha_step(const int K, float (&a)[KA], float (&w)[KA], const Tables& t, const int row,
                                            const float4* e, Diag& dg)
 {
-  if constexpr (KT > 0 && kPacked) {
-    alpha_step_pk<KT, KA, SCALE, SY>(a, w, rowSetOf<KT>(t, row), t.cR, e, dg);
-  } else {
-    const size_t o = (size_t)row * t.KP;
-    alpha_step_1<KT, KA, SCALE>(K, a, w, t.D + o, t.B + o, t.U + o, t.cR, e, dg);
-    waitLgkm0();
-  }
+  (void)K;
+  alpha_step_pk<KT, KA, SCALE, SY>(a, w, rowSetOf<KT>(t, row), t.cR, e, dg);
 }
 
 // alpha at the first site of the window: pi * emission, scaled (HMM.cpp:736-747).
@@ -1222,19 +1008,19 @@ template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF, bool DUAL = false>
 __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(const KParams p)
 {
   static_assert(!HALF || (!SEQ && MODE == kModeIbd), "beta stride 2 is built for the array-mode IBD decode");
-  static_assert(!DUAL || (MODE == kModeIbd && !SEQ && KT > 0), "two half-groups per wave: array-mode IBD");
-  // array mode with a compile-time K: the backward loops are rotated (operand-free step tails overlap the next
-  // step's first operand requests)
-  constexpr bool kRotate = KT > 0 && kPacked && !SEQ;
-  constexpr int KA = KT > 0 ? KT : kMaxGenericK;
+  static_assert(KT > 0 && KT <= kMaxStates, "a member of the kernel family (fsmc_instances.h)");
+  static_assert(!DUAL || (MODE == kModeIbd && !SEQ), "two half-groups per wave: array-mode IBD");
+  // array mode: the backward loops are rotated (operand-free step tails overlap the next step's first operand requests)
+  constexpr bool kRotate = !SEQ;
+  constexpr int KA = KT;
   constexpr int K4A = (KA + 3) / 4;
   constexpr int E4A = ((KA + kKPad - 1) / kKPad) * (kKPad / 4); // float4 per emission row (rows padded to kKPad)
   constexpr int NC = SEQ ? 4 : 3;                         // emission rows per site: 3 observation classes (+ gap)
   constexpr int NL = (NC * E4A + kWave - 1) / kWave;      // float4 per lane to stage one site's rows
-  const int K = KT > 0 ? KT : p.K;
+  constexpr int K = KT;
   // states of the model: < K for a padded family member (the states Kreal..K-1 are ghosts), otherwise K
   const int Kreal = kGhost<KT> ? p.K : K;
-  const int K4 = (K + 3) >> 2;
+  constexpr int K4 = (K + 3) >> 2;
   const int KP = p.KP; // (a compile-time KP for fixed K measured 6 % slower on C2: keep the runtime value)
   const int E4 = KP >> 2;
 
@@ -1245,9 +1031,8 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   __shared__ float4 betaLds[kLandF4];
 
   const int lane = threadIdx.x;
-  const cfloat_p tD = (cfloat_p)p.D, tB = (cfloat_p)p.B, tU = (cfloat_p)p.U, tRR = (cfloat_p)p.RR;
   const cfloat_p tPi = (cfloat_p)p.pi, tCR = (cfloat_p)p.cR, tExpT = (cfloat_p)p.expT;
-  const Tables tabs = {tD, tB, tU, tRR, (cfloat_p)p.rowSets, tCR, (cfloat_p)p.ghostMask, KP};
+  const Tables tabs = {(cfloat_p)p.rowSets, tCR, (cfloat_p)p.ghostMask};
   const cint_p tStepRow = (cint_p)p.stepRow;
   const cint_p tRowGapF = (cint_p)p.rowGapF, tRowSiteB = (cint_p)(SEQ ? p.rowSiteB : p.stepRow),
                tRowGapB = (cint_p)p.rowGapB;
@@ -1276,10 +1061,19 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   for (unsigned round = 0;; ++round) {
     unsigned g = 0;
     if (MODE == kModeSums) {
-      // one group per wave and launch: wave i writes the batch sums of group groupBase + i into plane i, and the host
-      // adds the planes to the accumulator one after the other -- the reference's order, batch by batch
-      // (HMM.cpp:1054-1073)
-      g = round == 0 ? (unsigned)p.groupBase + blockIdx.x : (unsigned)p.nGroups;
+      // one BATCH per wave and launch: wave i writes the sums of batch groupBase + i into plane i, and the host adds the
+      // planes to the accumulator one after the other -- the reference's order, batch by batch (HMM.cpp:1054-1073).  A
+      // batch of more than 64 pairs is several consecutive groups (p.batchFirst: first group of every batch): the wave
+      // decodes them in turn and every group continues the batch's running sums where the group before left them.
+      if (p.batchFirst) {
+        const cuint_p bf = (cuint_p)p.batchFirst;
+        g = bf[p.groupBase + blockIdx.x] + round;
+        if (g >= bf[p.groupBase + blockIdx.x + 1]) {
+          g = (unsigned)p.nGroups;
+        }
+      } else {
+        g = round == 0 ? (unsigned)p.groupBase + blockIdx.x : (unsigned)p.nGroups;
+      }
     } else {
       if (lane == 0) {
         g = atomicAdd(&p.counters[p.groupBase], 1u);
@@ -1802,7 +1596,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
               if (4 * k4 + 3 < K) b[4 * k4 + 3] = o.w;
             }
           };
-          if constexpr (KT > 0 && kPacked) {
+          {
             const cfloat_p rs = rowSetOf<KT>(tabs, rowq);
             BetaOps<KT> ops;
             beta_issue_pk<KT>(ops, rs, eq); // in flight while the landed row moves from LDS to registers
@@ -1828,14 +1622,11 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
                 }
               }
             }
-          } else {
-            readLanded();
-            beta_step<KT, KA>(K, b, w, tabs, rowq, eq, cycW);
           }
           FSMC_END(cycW, 9);
 #pragma unroll
           for (int k = 0; k < K; k += 2) {
-            if (KT > 0 && k + 1 < K) { // products two states at a time, the sum in state order
+            if (k + 1 < K) { // products two states at a time, the sum in state order
               const f32x2 av = {a[k], a[k + 1]};
               const f32x2 bv = {b[k], b[k + 1]};
               const f32x2 q = pmul(av, bv);
@@ -1874,7 +1665,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
 #pragma unroll
             for (int i = 0; i < kCB; i += 2) {
               const int k = blk * kCB + i;
-              if (KT > 0 && k + 1 < K) {
+              if (k + 1 < K) {
                 const f32x2 av = {a[k], a[k + 1]};
                 const f32x2 bv = {pick(c0, c1, i), pick(c0, c1, i + 1)};
                 const f32x2 q = pmul(av, bv);
@@ -1951,7 +1742,16 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           for (int kk = lane; kk < Kreal; kk += kWave) {
+            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + kk;
             float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
+            if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
+              if (p.flags & FSMC_WANT_SUMS) s = acc[0];
+              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                s00 = acc[p.sumsPlane];
+                s01 = acc[2 * p.sumsPlane];
+                s11 = acc[3 * p.sumsPlane];
+              }
+            }
             for (int v = 0; v < nPairsInGroup; ++v) {
               const float q = tile[kk * 65 + v];
               s = s + q;
@@ -1966,7 +1766,6 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
                 }
               }
             }
-            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + kk;
             if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
             if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
               acc[p.sumsPlane] = s00;
@@ -2009,9 +1808,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             // the states beyond the threshold add +0.f, which leaves the (non-negative) sum unchanged.
             const unsigned nPost = p.stateThr;
             float s = 0.f;
-            if constexpr (KT > 0) {
-              scanBlocks<KA, KT, K4A>(w, s, cq, launderScalar(nPost));
-            }
+            scanBlocks<KA, KT, K4A>(w, s, cq, launderScalar(nPost));
             int level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
             if constexpr (DUAL) {
               if (!(pos >= mySF && pos < myST)) {

@@ -712,10 +712,19 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
   for (unsigned round = 0;; ++round) {
     unsigned g;
     if (MODE == kModeSums) {
-      // one group per workgroup and launch: workgroup i writes the batch sums of group groupBase + i into plane i, and
-      // the host adds the planes to the accumulator one after the other -- the reference's order, batch by batch
-      // (HMM.cpp:1054-1073)
-      g = round == 0 ? (unsigned)p.groupBase + blockIdx.x : (unsigned)p.nGroups;
+      // one BATCH per workgroup and launch: workgroup i writes the sums of batch groupBase + i into plane i, and the
+      // host adds the planes to the accumulator one after the other -- the reference's order, batch by batch
+      // (HMM.cpp:1054-1073); the groups of a batch of more than 64 pairs are decoded in turn and continue the batch's
+      // running sums (fsmc_kernels.h)
+      if (p.batchFirst) {
+        const cuint_p bf = (cuint_p)p.batchFirst;
+        g = bf[p.groupBase + blockIdx.x] + round;
+        if (g >= bf[p.groupBase + blockIdx.x + 1]) {
+          g = (unsigned)p.nGroups;
+        }
+      } else {
+        g = round == 0 ? (unsigned)p.groupBase + blockIdx.x : (unsigned)p.nGroups;
+      }
     } else {
       if (threadIdx.x == 0) {
         groupLds = atomicAdd(&p.counters[p.groupBase], 1u);
@@ -1176,7 +1185,16 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
           __builtin_amdgcn_wave_barrier();
           const int state = h * KH + lane;
           if (lane < KH && state < K) {
+            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + state;
             float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
+            if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
+              if (p.flags & FSMC_WANT_SUMS) s = acc[0];
+              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                s00 = acc[p.sumsPlane];
+                s01 = acc[2 * p.sumsPlane];
+                s11 = acc[3 * p.sumsPlane];
+              }
+            }
             for (int v = 0; v < nPairsInGroup; ++v) {
               const float q = tile[lane * kWave + ((v + lane) & (kWave - 1))];
               s = s + q;
@@ -1191,7 +1209,6 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
                 }
               }
             }
-            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + state;
             if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
             if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
               acc[p.sumsPlane] = s00;

@@ -3,11 +3,18 @@
 #include "data.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <exception>
 #include <iostream>
+#include <mutex>
 #include <random>
 #include <stdexcept>
+#include <thread>
 
 #include "util.hpp"
 
@@ -88,6 +95,120 @@ int sampleHypergeometric(int populationSize, int numberOfSuccesses, int sampleSi
     ret += samplingVector[static_cast<size_t>(i)];
   }
   return ret;
+}
+
+// Host threads of the start-up work (parsing, bit transposes, the emission preparation's shuffles): the machine's, at
+// most 16 (a GPU box gives a rank that many), FSMC_HOST_THREADS overrides.
+unsigned hostThreads()
+{
+  if (const char* e = std::getenv("FSMC_HOST_THREADS")) {
+    const int v = std::atoi(e);
+    if (v >= 1) {
+      return static_cast<unsigned>(std::min(v, 256));
+    }
+  }
+  const unsigned hw = std::thread::hardware_concurrency();
+  return std::max(1u, std::min(hw ? hw : 1u, 16u));
+}
+
+// body(i) for i in [0, n), dynamically scheduled over the host threads; the first exception is rethrown
+template <typename F> void parallelFor(size_t n, F&& body)
+{
+  const unsigned T = static_cast<unsigned>(std::min<size_t>(hostThreads(), n));
+  if (T <= 1) {
+    for (size_t i = 0; i < n; ++i) {
+      body(i);
+    }
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::exception_ptr err;
+  std::mutex errMutex;
+  auto work = [&]() {
+    try {
+      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+        body(i);
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(errMutex);
+      if (!err) {
+        err = std::current_exception();
+      }
+      next.store(n);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < T; ++t) {
+    pool.emplace_back(work);
+  }
+  work();
+  for (std::thread& t : pool) {
+    t.join();
+  }
+  if (err) {
+    std::rethrow_exception(err);
+  }
+}
+
+// In-place transpose of a 64 x 64 bit matrix held as 64 words (row i = word i, column j = bit j).
+void transpose64(uint64_t (&a)[64])
+{
+  uint64_t m = 0x00000000FFFFFFFFull;
+  for (int j = 32; j != 0; j >>= 1, m ^= (m << j)) {
+    for (int k = 0; k < 64; k = (k + j + 1) & ~j) {
+      const uint64_t t = ((a[k] >> j) ^ a[k + j]) & m;
+      a[k] ^= t << j;
+      a[k + j] ^= t;
+    }
+  }
+}
+
+// The allele characters of a haps line, packed: `a` points at the separator in front of the first allele, the allele of
+// haplotype i is a[2*i + 1] ('0' or '1', Data.cpp:465-471).  Writes ceil(n / 64) words (bit i = haplotype i carries '1'),
+// returns false when a character is neither.
+bool packAlleles(const char* a, size_t n, uint64_t* out)
+{
+  const size_t words = (n + 63) / 64;
+  unsigned char bad = 0;
+  size_t i = 0;
+  for (size_t w = 0; w < words; ++w) {
+    uint64_t acc = 0;
+    const size_t end = std::min(n, (w + 1) * 64);
+    int bit = 0;
+    // four haplotypes per 8-byte load: their characters sit in bytes 1, 3, 5, 7; '0' = 0x30, '1' = 0x31
+    for (; i + 4 <= end; i += 4, bit += 4) {
+      uint64_t x;
+      std::memcpy(&x, a + 2 * i, 8);
+      const uint64_t c = (x >> 8) & 0x00FF00FF00FF00FFull;
+      bad |= static_cast<unsigned char>((((c & 0x00FE00FE00FE00FEull) ^ 0x0030003000300030ull) != 0) ? 1 : 0);
+      const uint64_t y = c & 0x0001000100010001ull;
+      acc |= ((y * 0x0001000200040008ull) >> 48 & 0xFull) << bit; // bits 0, 16, 32, 48 -> 51, 50, 49, 48 ... see below
+    }
+    for (; i < end; ++i, ++bit) {
+      const unsigned char ch = static_cast<unsigned char>(a[2 * i + 1]);
+      bad |= static_cast<unsigned char>((ch & 0xFE) != 0x30);
+      acc |= static_cast<uint64_t>(ch & 1u) << bit;
+    }
+    out[w] = acc;
+  }
+  return bad == 0;
+}
+
+// dst bits [dstPos, dstPos + n) = src bits [srcPos, srcPos + n) (dst bits there are zero on entry)
+void copyBits(uint64_t* dst, size_t dstPos, const uint64_t* src, size_t srcPos, size_t n)
+{
+  while (n) {
+    const size_t so = srcPos & 63, dof = dstPos & 63;
+    const size_t take = std::min<size_t>(n, std::min<size_t>(64 - so, 64 - dof));
+    uint64_t v = src[srcPos >> 6] >> so;
+    if (take < 64) {
+      v &= (1ull << take) - 1;
+    }
+    dst[dstPos >> 6] |= v << dof;
+    srcPos += take;
+    dstPos += take;
+    n -= take;
+  }
 }
 
 } // namespace

@@ -138,8 +138,12 @@ std::vector<HashingCandidate> HashingPrefilter::runOnDevice(fsmc_ctx* ctx) const
   };
   int rc = call();
   if (rc == FSMC_EOVERFLOW) {
+    // (nobody knows the count beforehand: the library finished the list on the device and kept it)
     buf.resize(n);
-    rc = call();
+    rc = fsmc_identify_fetch(ctx, buf.data(), buf.size(), &n);
+    if (rc != FSMC_OK) {
+      rc = call();
+    }
   }
   if (rc != FSMC_OK) {
     throw std::runtime_error(std::string("fsmc_identify: ") + fsmc_last_error(ctx));

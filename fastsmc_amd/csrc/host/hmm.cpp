@@ -576,6 +576,9 @@ void HMM::closeBatch(bool last)
       off = take;
     }
   }
+  if (!packLanes) {
+    mBatchFirstGroup.push_back(static_cast<uint32_t>(mGroups.size()));
+  }
   for (; off < n; off += 64) {
     fsmc_group g{};
     g.first_pair = static_cast<uint32_t>(mBatchBegin + off);
@@ -618,11 +621,16 @@ void HMM::flush()
   }
   if (mParams.doPosteriorSums || mParams.doMajorMinorPosteriorSums) {
     const bool mm = mParams.doMajorMinorPosteriorSums;
+    // the reference sums a WHOLE batch over its pairs and then adds it (HMM.cpp:1054-1073): the groups of a batch of more
+    // than 64 pairs share one running sum on the device
+    mBatchFirstGroup.push_back(static_cast<uint32_t>(mGroups.size()));
     check(mCtx,
-          fsmc_decode_sums(mCtx, mModel, mParams.doPosteriorSums ? mReturn.sumOverPairs.data() : nullptr,
-                           mm ? mReturn.sumOverPairs00.data() : nullptr, mm ? mReturn.sumOverPairs01.data() : nullptr,
-                           mm ? mReturn.sumOverPairs11.data() : nullptr),
-          "fsmc_decode_sums");
+          fsmc_decode_sums_batches(mCtx, mModel, mBatchFirstGroup.data(), mBatchFirstGroup.size() - 1,
+                                   mParams.doPosteriorSums ? mReturn.sumOverPairs.data() : nullptr,
+                                   mm ? mReturn.sumOverPairs00.data() : nullptr,
+                                   mm ? mReturn.sumOverPairs01.data() : nullptr,
+                                   mm ? mReturn.sumOverPairs11.data() : nullptr),
+          "fsmc_decode_sums_batches");
   }
   if (!mParams.FastSMC && (mStoreMean || mStoreMap || mStorePosterior || mStoreSumOfPosterior)) {
     // writePerPairOutput (HMM.cpp:1360-1458)
@@ -683,6 +691,7 @@ void HMM::flush()
   std::vector<fsmc_pair> rest(mPairs.begin() + static_cast<long>(mBatchBegin), mPairs.end());
   mPairs.swap(rest);
   mGroups.clear();
+  mBatchFirstGroup.clear();
   mBatchBegin = 0;
 }
 

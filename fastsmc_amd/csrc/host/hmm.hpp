@@ -181,6 +181,7 @@ private:
   // work list under construction
   std::vector<fsmc_pair> mPairs;
   std::vector<fsmc_group> mGroups;
+  std::vector<uint32_t> mBatchFirstGroup; // posterior sums: first group of every closed batch (a batch > 64 pairs is several groups)
   size_t mBatchBegin = 0; // first pair of the open batch
   std::vector<unsigned> mFromBatch, mToBatch; // per slot of the open batch (hashing mode), HMM.cpp:491-493
   unsigned long mHashingCount = 0;            // "cpt"

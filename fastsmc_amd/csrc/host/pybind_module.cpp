@@ -79,6 +79,11 @@ std::vector<std::vector<float>> asMat(const py::array_t<float, py::array::c_styl
 
 } // namespace
 
+namespace fsmc_host
+{
+void bindContainers(py::module_& m); // pybind_containers.cpp: VectorBool ... UMapIntToVectorFloat (pybind.cpp:63-70)
+}
+
 PYBIND11_MODULE(_pyasmc, m)
 {
   m.doc() = "MI355X-native drop-in for the decode path of PalamaraLab/FastSMC (pyASMC-compatible names)";
@@ -509,4 +514,5 @@ PYBIND11_MODULE(_pyasmc, m)
   m.def("dipToHapId", &dipToHapId);
   m.def("indPlusHapToCombinedId", &indPlusHapToCombinedId);
   m.def("combinedIdToIndPlusHap", &combinedIdToIndPlusHap);
+  fsmc_host::bindContainers(m);
 }

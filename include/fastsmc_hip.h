@@ -42,6 +42,7 @@ extern "C" {
 #define FSMC_ESTATE (-5)    /* call sequence error (e.g. decode before upload) */
 #define FSMC_EOVERFLOW (-6) /* caller's output buffer too small; *n_out holds the needed count */
 #define FSMC_EUNSUPPORTED (-7)
+#define FSMC_ERUNTIME (-8)  /* the device is there but this process cannot launch on it: two HIP runtimes loaded */
 
 typedef struct fsmc_ctx fsmc_ctx;
 typedef struct fsmc_model fsmc_model;
@@ -187,6 +188,10 @@ typedef struct {
 int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_t n_words, const uint32_t* global_ids,
                   const fsmc_job_window* job, const float* gen_pos, uint32_t n_sites, int32_t gap, float skip,
                   float min_m, fsmc_candidate* out, size_t cap, size_t* n_out);
+/* After an fsmc_identify that returned FSMC_EOVERFLOW (*n_out = the count): the complete candidate list of that call, in
+ * emission order -- it was finished and kept on the device, so the caller allocates *n_out records and fetches them
+ * instead of running the identification a second time.  The kept list is released by the fetch. */
+int fsmc_identify_fetch(fsmc_ctx* ctx, fsmc_candidate* out, size_t cap, size_t* n_out);
 
 int fsmc_sync(fsmc_ctx* ctx);
 /* Device time (ms, hipEvent) of the last decode launch's kernel(s); valid after a sync/fetch. */
@@ -213,6 +218,13 @@ int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model* m, const float* exp_co
 /* augmentSumOverPairs: sums[S][K] += sum over the pairs of the work list of the posterior
  * (and the 00/01/11 split when the pointers are non-NULL).  Whole-sequence groups only. */
 int fsmc_decode_sums(fsmc_ctx* ctx, const fsmc_model* m, float* sums, float* sums00, float* sums01, float* sums11);
+/* The same for reference batches of more than 64 pairs (DecodingParams.cpp:301 allows any multiple of 8): the reference
+ * sums a whole batch over its pairs, in order, and then adds it (HMM.cpp:1054-1073).  Batch b is the consecutive groups
+ * batch_first_group[b] .. batch_first_group[b+1]-1 (n_batches + 1 entries, the first 0, the last the number of groups):
+ * they are decoded in turn and share one running sum, so the result is the reference's bit for bit.
+ * fsmc_decode_sums treats every group as a batch of its own. */
+int fsmc_decode_sums_batches(fsmc_ctx* ctx, const fsmc_model* m, const uint32_t* batch_first_group, size_t n_batches,
+                             float* sums, float* sums00, float* sums01, float* sums11);
 
 #ifdef __cplusplus
 }

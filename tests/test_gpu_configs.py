@@ -6,7 +6,7 @@ determinism).  C2 has its own file (test_gpu_full_size.py).
       of the no-hashing regression shape (test_fastsmc_regression.cpp:97-161), synthetic map + 69-state model:
       FastSMC.run() text byte-identical to oracle + record formatter.
   C3  the per-GPU shard shape of the 10 000 x 100 000 cohort: windows of 100 000 sites, K = 69 (49 chunks).
-  C4  K = 256, windows of 200 000 sites through the chunked four-lanes-per-pair kernel.
+  C4  K = 256, windows of 200 000 sites through the chunked wave-group kernel (four waves per group, lane = pair).
   C5  the hashing regime: 10 240 batches of 32 pairs, each with its own window of 320 ... 5504 sites.
 """
 import copy

@@ -151,3 +151,32 @@ def test_hmm_decode_all_posterior_sums(small_problem, tmp_path):
         O.augment_sum_over_pairs(pm, post, len(chunk), ob, hb, want)
     assert got.shape == (pm.S, pm.K)
     np.testing.assert_array_equal(got, want)
+
+
+def test_hmm_posterior_sums_with_a_batch_size_of_128(small_problem, tmp_path):
+    """batchSize = 128 through the host API: two groups per batch on the device, one running sum per batch
+    (HMM.cpp:1054-1073)."""
+    sp = small_problem
+    root = str(tmp_path / "asmc3")
+    _write_files(sp, root)
+    p = api.DecodingParams(root, root + ".decodingQuantFile.missing", doPosteriorSums=True)
+    p.decodingQuantFile = root + ".decodingQuantities.gz"
+    p.useKnownSeed = True
+    p.batchSize = 128
+    data = api.Data(p)
+    hmm = api.HMM(data, p)
+    hmm.decodeAll(1, 1)
+    got = hmm.getDecodingReturnValues().sumOverPairs
+    gen = np.array(data.geneticPositions, np.float32)
+    _, derived, _ = synth.fold_and_pack(sp["haps"].alleles)
+    pm = O.prepare_model(sp["tables"], gen, sp["haps"].bp, derived, 64, time=p.time, no_conditional_age_estimates=False)
+    pairs = O.enumerate_all_pairs(32)
+    want = np.zeros((pm.S, pm.K), np.float32)
+    folded = sp["folded"]
+    for b0 in range(0, len(pairs), 128):
+        chunk = pairs[b0:b0 + 128]
+        ob = np.stack([folded[x] ^ folded[y] for x, y in chunk])
+        hb = np.stack([folded[x] & folded[y] for x, y in chunk])
+        post, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
+        O.augment_sum_over_pairs(pm, post, len(chunk), ob, hb, want)
+    np.testing.assert_array_equal(got, want)

@@ -74,3 +74,36 @@ def test_sums_continue_over_two_calls_like_two_flushes():
     for got, w in zip(acc[1], want[1:]):
         np.testing.assert_array_equal(got, w)
     ctx.close()
+
+
+@pytest.mark.parametrize("K,batch", [(69, 128), (69, 200), (150, 136)])
+def test_sums_of_batches_larger_than_a_wavefront(K, batch, monkeypatch):
+    """batchSize only has to be a multiple of 8 (DecodingParams.cpp:301): the reference sums a WHOLE batch over its
+    pairs in order and then adds it (HMM.cpp:1054-1073).  A batch of more than 64 pairs is several groups here; they
+    share one running sum (fsmc_decode_sums_batches), so the result is still the reference's bit for bit -- also when a
+    launch holds fewer batches than there are and with a ragged last batch."""
+    pm, bits, folded = _problem(K=K, n_hap=64, S=400, seed=11)
+    pairs = O.enumerate_all_pairs(32)
+    pairs = pairs[: 3 * batch + 77]
+    want = _oracle_sums(pm, folded, pairs, batch)
+    ctx = capi.Context(0)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    groups, first = [], []
+    for lo in range(0, len(pairs), batch):
+        n = min(batch, len(pairs) - lo)
+        first.append(len(groups))
+        for off in range(0, n, 64):
+            groups.append((lo + off, min(64, n - off), 0, pm.S, 0, pm.S))
+    first.append(len(groups))
+    ctx.upload_worklist(pr, np.array(groups, dtype=capi.GROUP_DTYPE))
+    monkeypatch.setenv("FSMC_DIAG_SUMS_SLOTS", "2")
+    s, mm = ctx.decode_sums(model, major_minor=True, batch_first_group=first)
+    np.testing.assert_array_equal(s, want[0])
+    for got, w in zip(mm, want[1:]):
+        np.testing.assert_array_equal(got, w)
+    # the batches must partition the group list
+    with pytest.raises(RuntimeError):
+        ctx.decode_sums(model, batch_first_group=first[:-1])
+    ctx.close()
