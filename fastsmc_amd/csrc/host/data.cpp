@@ -10,6 +10,7 @@
 #include <cstring>
 #include <deque>
 #include <exception>
+#include <memory>
 #include <iostream>
 #include <mutex>
 #include <random>
@@ -77,24 +78,6 @@ bool splitHapsLine(const std::string& line, std::string (&field)[5], size_t& res
   }
   restBegin = p;
   return true;
-}
-
-// Data::sampleHypergeometric (Data.cpp:144-160): glibc rand() seeds a libstdc++ mt19937 for std::shuffle.
-int sampleHypergeometric(int populationSize, int numberOfSuccesses, int sampleSize)
-{
-  if (numberOfSuccesses < 0 || numberOfSuccesses > populationSize) {
-    return -1;
-  }
-  std::vector<unsigned short> samplingVector(static_cast<size_t>(populationSize), 0);
-  for (int i = 0; i < numberOfSuccesses; i++) {
-    samplingVector[static_cast<size_t>(i)] = 1;
-  }
-  std::shuffle(samplingVector.begin(), samplingVector.end(), std::mt19937(std::rand()));
-  int ret = 0;
-  for (int i = 0; i < sampleSize; i++) {
-    ret += samplingVector[static_cast<size_t>(i)];
-  }
-  return ret;
 }
 
 // Host threads of the start-up work (parsing, bit transposes, the emission preparation's shuffles): the machine's, at
@@ -182,7 +165,9 @@ bool packAlleles(const char* a, size_t n, uint64_t* out)
       const uint64_t c = (x >> 8) & 0x00FF00FF00FF00FFull;
       bad |= static_cast<unsigned char>((((c & 0x00FE00FE00FE00FEull) ^ 0x0030003000300030ull) != 0) ? 1 : 0);
       const uint64_t y = c & 0x0001000100010001ull;
-      acc |= ((y * 0x0001000200040008ull) >> 48 & 0xFull) << bit; // bits 0, 16, 32, 48 -> 51, 50, 49, 48 ... see below
+      // (bits 0, 16, 32, 48 of y land on bits 48, 49, 50, 51 of the product; the other partial products fall on distinct
+      //  lower bits or beyond bit 63: no carries)
+      acc |= (((y * 0x0001000200040008ull) >> 48) & 0xFull) << bit;
     }
     for (; i < end; ++i, ++bit) {
       const unsigned char ch = static_cast<unsigned char>(a[2 * i + 1]);
@@ -308,7 +293,9 @@ Data::Data(const DecodingParams& params)
   foldToMinorAlleles = params.foldData;
   decodingUsesCSFS = params.usingCSFS;
 
-  sites = countHapLines(root);
+  // FastSMC mode reads the haps file ONCE (the reference counts its lines first, Data.cpp:264-287, then reads it, then
+  // reads it again for the hashing words): the number of sites is known when the single pass ends
+  sites = params.FastSMC ? 0 : countHapLines(root);
   sampleSize = static_cast<unsigned long>(countSamplesLines(root));
   haploidSampleSize = sampleSize * 2ul;
   siteWasFlippedDuringFolding.assign(static_cast<size_t>(sites), false);
@@ -321,11 +308,11 @@ Data::Data(const DecodingParams& params)
   }
   setupJobWindows(params.jobInd, params.jobs);
   readSamplesList(root, params.jobInd, params.jobs);
-  allocateBits();
   if (params.FastSMC) {
     const auto geneticMap = readMapFastSMC(root);
-    readHapsFastSMC(root, params.jobInd, params.jobs, geneticMap);
+    readHapsFastSMC(root, params.jobInd, params.jobs, geneticMap); // (sets `sites`, allocates and fills the bit matrix)
   } else {
+    allocateBits();
     readHapsAsmc(root);
     readMapAsmc(root);
   }
@@ -394,80 +381,310 @@ void Data::addMarkerFromMap(unsigned long bp, const std::vector<std::pair<unsign
 void Data::readHapsFastSMC(const std::string& inFileRoot, int jobID, int jobs,
                            const std::vector<std::pair<unsigned long, double>>& geneticMap)
 {
-  // Data.cpp:397-521
-  LineReader br(hapsPath(inFileRoot));
-  totalSamplesCount.assign(static_cast<size_t>(sites), 0);
-  derivedAlleleCounts.assign(static_cast<size_t>(sites), 0);
-  std::string line;
-  std::string field[5];
-  unsigned long largestBp = 0;
-  unsigned pos = 0;
-  unsigned curG = 0;
+  // Data.cpp:397-521, as ONE pass over the file and on every host core: a reader thread inflates the file and cuts it
+  // into blocks of whole lines; worker threads parse the blocks -- fields, allele count, the loaded haplotypes' alleles
+  // packed 64 to a word, one row of words per SITE --; the blocks are then joined in file order (position checks,
+  // genetic-map interpolation: the sequential part, Data.cpp:523-565) and the site-major bit rows transposed into the
+  // haplotype-major matrix the device wants.  At the 10 000-haplotype x 100 000-site shape the text is 2 GB: the
+  // reference's two to three sequential passes over it (Data.cpp:264-287, 397-521, FastSMC.cpp:144-227) are what a
+  // multi-GPU run would wait for.
+  const size_t nHapsFile = 2 * sampleSize;
+  const size_t wordsFile = (nHapsFile + 63) / 64;
+  // the loaded individuals as ranges of haplotype columns (job windows select up to three ranges, Data.cpp:251-262)
+  std::vector<std::pair<size_t, size_t>> ranges; // [first hap, last hap) of the file
+  for (unsigned d = 0; d < sampleSize; d++) {
+    if (readSample(d, jobID, jobs)) {
+      if (!ranges.empty() && ranges.back().second == 2 * static_cast<size_t>(d)) {
+        ranges.back().second += 2;
+      } else {
+        ranges.emplace_back(2 * static_cast<size_t>(d), 2 * static_cast<size_t>(d) + 2);
+      }
+    }
+  }
+  const size_t nLoaded = numHapRows();
+  const size_t wordsLoaded = (nLoaded + 63) / 64;
   const int totalSamples = static_cast<int>(2 * sampleSize);
-  while (br.getline(line)) {
-    size_t rest = 0;
-    if (!splitHapsLine(line, field, rest)) {
-      continue;
-    }
-    const size_t restLen = line.size() - rest;
-    if (!(restLen == 4 * sampleSize || restLen == 4 * sampleSize + 1)) {
-      throw std::runtime_error("ERROR: haps line has wrong length. Length is " + std::to_string(restLen) +
-                               ", but should be 4 * " + std::to_string(sampleSize));
-    }
-    const unsigned long bp = std::stoul(field[2]);
-    if (bp > largestBp) {
-      largestBp = bp;
-    } else {
-      throw std::runtime_error("ERROR: rows in haps data file must be ordered by increasing physical position, but "
-                               "two consecutive values were " + std::to_string(largestBp) + " and " +
-                               std::to_string(bp));
-    }
-    if (pos == 0) {
-      const std::string chr = field[0].substr(0, field[0].find(':'));
-      try {
-        chrNumber = std::stoi(chr);
-      } catch (const std::exception&) {
-        chrNumber = 0;
+
+  struct Block {
+    std::vector<char> text; // whole lines, the last one newline-terminated or the file's last
+    size_t nLines = 0;      // lines of the block (every line counts as a site, like countHapLines)
+    size_t index = 0;       // position of the block in the file
+    // filled by the worker:
+    size_t nRows = 0; // lines that are haps rows (five fields)
+    std::vector<unsigned long> bp;
+    std::vector<int> da;
+    std::vector<char> flipped;
+    std::vector<uint64_t> rows; // [nRows][wordsLoaded]
+    std::string firstChrField;
+  };
+  std::deque<std::unique_ptr<Block>> todo;
+  std::vector<std::unique_ptr<Block>> done; // by block index
+  std::mutex mu;
+  std::condition_variable cvWork, cvRoom;
+  bool eof = false;
+  std::exception_ptr err;
+  const unsigned T = hostThreads();
+  const size_t maxQueued = 2 * static_cast<size_t>(T) + 2;
+  size_t blocksMade = 0;
+
+  auto parseBlock = [&](Block& blk) {
+    blk.bp.reserve(blk.nLines);
+    blk.da.reserve(blk.nLines);
+    blk.flipped.reserve(blk.nLines);
+    blk.rows.assign(blk.nLines * wordsLoaded, 0ull);
+    std::vector<uint64_t> all(wordsFile);
+    const char* p = blk.text.data();
+    const char* const end = p + blk.text.size();
+    while (p < end) {
+      const char* nl = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+      const char* le = nl ? nl : end; // line = [p, le)
+      // the five leading fields (Data.cpp:413-428)
+      const char* q = p;
+      const char* fb[5];
+      const char* fe[5];
+      bool ok = true;
+      for (int f = 0; f < 5; ++f) {
+        while (q < le && std::isspace(static_cast<unsigned char>(*q))) {
+          ++q;
+        }
+        if (q >= le) {
+          ok = false;
+          break;
+        }
+        fb[f] = q;
+        while (q < le && !std::isspace(static_cast<unsigned char>(*q))) {
+          ++q;
+        }
+        fe[f] = q;
       }
-      if (chrNumber <= 0 || chrNumber > 1260) {
-        chrNumber = 0;
-      }
-    }
-    if (pos >= static_cast<unsigned>(sites)) {
-      break;
-    }
-    addMarkerFromMap(bp, geneticMap, curG, pos);
-    const char* a = line.data() + rest;
-    int DAcount = 0;
-    for (unsigned i = 0; i < 2 * sampleSize; i++) {
-      const char c = a[2 * i + 1];
-      if (c == '1') {
-        DAcount++;
-      } else if (c != '0') {
-        throw std::runtime_error("ERROR: hap is not '0' or '1'");
-      }
-    }
-    totalSamplesCount[pos] = totalSamples;
-    const bool minorAlleleValue = foldToMinorAlleles ? (DAcount <= totalSamples - DAcount) : true;
-    siteWasFlippedDuringFolding[pos] = !minorAlleleValue;
-    size_t row = 0;
-    for (unsigned d = 0; d < sampleSize; d++) {
-      if (readSample(d, jobID, jobs)) {
-        for (unsigned h = 0; h < 2; ++h) {
-          const bool isOne = a[2 * (2 * d + h) + 1] == '1';
-          if (isOne == minorAlleleValue) {
-            setBit(row + h, pos);
+      if (ok) {
+        const size_t restLen = static_cast<size_t>(le - q);
+        if (!(restLen == 4 * sampleSize || restLen == 4 * sampleSize + 1)) {
+          throw std::runtime_error("ERROR: haps line has wrong length. Length is " + std::to_string(restLen) +
+                                   ", but should be 4 * " + std::to_string(sampleSize));
+        }
+        if (blk.nRows == 0) {
+          blk.firstChrField.assign(fb[0], fe[0]);
+        }
+        blk.bp.push_back(std::stoul(std::string(fb[2], fe[2])));
+        if (!packAlleles(q, nHapsFile, all.data())) {
+          throw std::runtime_error("ERROR: hap is not '0' or '1'");
+        }
+        int DAcount = 0;
+        for (size_t w = 0; w < wordsFile; ++w) {
+          DAcount += __builtin_popcountll(all[w]);
+        }
+        const bool minorAlleleValue = foldToMinorAlleles ? (DAcount <= totalSamples - DAcount) : true;
+        blk.flipped.push_back(minorAlleleValue ? 0 : 1);
+        blk.da.push_back(foldToMinorAlleles ? std::min(DAcount, totalSamples - DAcount) : DAcount);
+        if (!minorAlleleValue) { // the stored bit says "carries the minor allele"
+          for (size_t w = 0; w < wordsFile; ++w) {
+            all[w] = ~all[w];
           }
         }
-        row += 2;
+        uint64_t* row = &blk.rows[blk.nRows * wordsLoaded];
+        size_t dst = 0;
+        for (const auto& r : ranges) {
+          copyBits(row, dst, all.data(), r.first, r.second - r.first);
+          dst += r.second - r.first;
+        }
+        blk.nRows++;
+      }
+      p = nl ? nl + 1 : end;
+    }
+    blk.rows.resize(blk.nRows * wordsLoaded);
+    std::vector<char>().swap(blk.text);
+  };
+
+  auto worker = [&]() {
+    for (;;) {
+      std::unique_ptr<Block> blk;
+      size_t idx = 0;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cvWork.wait(lock, [&] { return !todo.empty() || eof || err; });
+        if (err || (todo.empty() && eof)) {
+          return;
+        }
+        blk = std::move(todo.front());
+        todo.pop_front();
+        idx = blk->index;
+        cvRoom.notify_one();
+      }
+      try {
+        parseBlock(*blk);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!err) {
+          err = std::current_exception();
+        }
+        cvWork.notify_all();
+        cvRoom.notify_all();
+        return;
+      }
+      std::lock_guard<std::mutex> lock(mu);
+      if (done.size() <= idx) {
+        done.resize(idx + 1);
+      }
+      done[idx] = std::move(blk);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < T; ++t) {
+    pool.emplace_back(worker);
+  }
+  // the reader: inflate, cut at line ends
+  try {
+    gzFile f = gzopen(hapsPath(inFileRoot).c_str(), "rb");
+    if (!f) {
+      throw std::runtime_error("ERROR: could not open " + hapsPath(inFileRoot));
+    }
+    gzbuffer(f, 1u << 20);
+    size_t kBlockBytes = 8u << 20;
+    if (const char* e = std::getenv("FSMC_HOST_BLOCK_BYTES")) { // tests: many blocks from a small file
+      const long v = std::atol(e);
+      if (v >= 64) {
+        kBlockBytes = static_cast<size_t>(v);
       }
     }
-    derivedAlleleCounts[pos] = foldToMinorAlleles ? std::min(DAcount, totalSamples - DAcount) : DAcount;
-    pos++;
+    std::vector<char> carry;
+    bool more = true;
+    while (more) {
+      auto blk = std::make_unique<Block>();
+      blk->text.resize(carry.size() + kBlockBytes);
+      std::memcpy(blk->text.data(), carry.data(), carry.size());
+      size_t have = carry.size();
+      carry.clear();
+      const int got = gzread(f, blk->text.data() + have, static_cast<unsigned>(kBlockBytes));
+      if (got < 0) {
+        gzclose(f);
+        throw std::runtime_error("ERROR: could not read " + hapsPath(inFileRoot));
+      }
+      have += static_cast<size_t>(got);
+      more = got > 0 && !gzeof(f);
+      if (got == 0) {
+        more = false;
+      }
+      blk->text.resize(have);
+      if (more) { // keep the unfinished last line for the next block
+        size_t cut = have;
+        while (cut > 0 && blk->text[cut - 1] != '\n') {
+          --cut;
+        }
+        carry.assign(blk->text.begin() + static_cast<long>(cut), blk->text.end());
+        blk->text.resize(cut);
+      }
+      if (blk->text.empty()) {
+        continue;
+      }
+      size_t lines = 0;
+      for (const char* c = blk->text.data(), *e = c + blk->text.size(); c < e;) {
+        const char* nl = static_cast<const char*>(std::memchr(c, '\n', static_cast<size_t>(e - c)));
+        lines++;
+        c = nl ? nl + 1 : e;
+      }
+      blk->nLines = lines;
+      blk->index = blocksMade++;
+      std::unique_lock<std::mutex> lock(mu);
+      cvRoom.wait(lock, [&] { return todo.size() < maxQueued || err; });
+      if (err) {
+        break;
+      }
+      todo.push_back(std::move(blk));
+      cvWork.notify_one();
+    }
+    gzclose(f);
+  } catch (...) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!err) {
+      err = std::current_exception();
+    }
   }
-  if (pos != static_cast<unsigned>(sites)) {
-    throw std::runtime_error("ERROR: read " + std::to_string(pos) + " haps rows, expected " + std::to_string(sites));
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    eof = true;
   }
+  cvWork.notify_all();
+  for (std::thread& t : pool) {
+    t.join();
+  }
+  if (err) {
+    std::rethrow_exception(err);
+  }
+
+  // ---- join the blocks in file order (the sequential part: Data.cpp:431-452, 523-565)
+  size_t nLinesTotal = 0, nRowsTotal = 0;
+  for (const auto& blk : done) {
+    nLinesTotal += blk->nLines;
+    nRowsTotal += blk->nRows;
+  }
+  sites = static_cast<int>(nLinesTotal);
+  if (nRowsTotal != nLinesTotal) {
+    throw std::runtime_error("ERROR: read " + std::to_string(nRowsTotal) + " haps rows, expected " + std::to_string(sites));
+  }
+  siteWasFlippedDuringFolding.assign(static_cast<size_t>(sites), false);
+  totalSamplesCount.assign(static_cast<size_t>(sites), totalSamples);
+  derivedAlleleCounts.assign(static_cast<size_t>(sites), 0);
+  geneticPositions.reserve(static_cast<size_t>(sites));
+  physicalPositions.reserve(static_cast<size_t>(sites));
+  recRateAtMarker.reserve(static_cast<size_t>(sites));
+  unsigned long largestBp = 0;
+  unsigned pos = 0, curG = 0;
+  std::vector<size_t> firstRow(done.size() + 1, 0);
+  for (size_t bI = 0; bI < done.size(); ++bI) {
+    const Block& blk = *done[bI];
+    firstRow[bI + 1] = firstRow[bI] + blk.nRows;
+    for (size_t r = 0; r < blk.nRows; ++r, ++pos) {
+      const unsigned long bp = blk.bp[r];
+      if (bp > largestBp) {
+        largestBp = bp;
+      } else {
+        throw std::runtime_error("ERROR: rows in haps data file must be ordered by increasing physical position, but "
+                                 "two consecutive values were " + std::to_string(largestBp) + " and " +
+                                 std::to_string(bp));
+      }
+      if (pos == 0) {
+        const std::string chr = blk.firstChrField.substr(0, blk.firstChrField.find(':'));
+        try {
+          chrNumber = std::stoi(chr);
+        } catch (const std::exception&) {
+          chrNumber = 0;
+        }
+        if (chrNumber <= 0 || chrNumber > 1260) {
+          chrNumber = 0;
+        }
+      }
+      addMarkerFromMap(bp, geneticMap, curG, pos);
+      siteWasFlippedDuringFolding[pos] = blk.flipped[r] != 0;
+      derivedAlleleCounts[pos] = blk.da[r];
+    }
+  }
+  // ---- site-major rows -> the haplotype-major matrix: 64 sites x 64 haplotypes at a time, all cores
+  allocateBits();
+  const size_t siteBlocks = (static_cast<size_t>(sites) + 63) / 64;
+  auto rowOfSite = [&](size_t site) -> const uint64_t* {
+    const size_t bI = static_cast<size_t>(std::upper_bound(firstRow.begin(), firstRow.end(), site) - firstRow.begin()) - 1;
+    return &done[bI]->rows[(site - firstRow[bI]) * wordsLoaded];
+  };
+  parallelFor(siteBlocks, [&](size_t sb) {
+    const size_t s0 = sb * 64;
+    const size_t nS = std::min<size_t>(64, static_cast<size_t>(sites) - s0);
+    const uint64_t* src[64];
+    for (size_t i = 0; i < nS; ++i) {
+      src[i] = rowOfSite(s0 + i);
+    }
+    for (size_t j = 0; j < wordsLoaded; ++j) {
+      uint64_t a[64];
+      for (size_t i = 0; i < 64; ++i) {
+        a[i] = i < nS ? src[i][j] : 0ull;
+      }
+      transpose64(a);
+      const size_t nH = std::min<size_t>(64, nLoaded - 64 * j);
+      for (size_t k = 0; k < nH; ++k) {
+        bits[(64 * j + k) * wordsPerHap + sb] = a[k];
+      }
+    }
+  });
 }
 
 void Data::readHapsAsmc(const std::string& inFileRoot)
@@ -629,9 +846,20 @@ std::vector<Individual> Data::individuals() const
 
 std::vector<std::vector<int>> Data::calculateUndistinguishedCounts(const int numCsfsSamples) const
 {
-  // Data.cpp:567-599
-  std::vector<std::vector<int>> undistinguished(derivedAlleleCounts.size(), std::vector<int>(3));
-  for (size_t i = 0; i < derivedAlleleCounts.size(); ++i) {
+  // Data.cpp:567-599.  A draw shuffles a vector of totalSamples - 2 entries with a generator seeded from std::rand()
+  // (Data.cpp:144-160): 3 x sites shuffles of cohort size -- 3 G element moves at the 10 000-haplotype x 100 000-site
+  // shape.  Only the SEEDS depend on each other (the std::rand() sequence, in site and `distinguished` order, drawn only
+  // where the reference draws): they are taken sequentially, the shuffles then run on every host core.
+  const size_t n = derivedAlleleCounts.size();
+  std::vector<std::vector<int>> undistinguished(n, std::vector<int>(3));
+  struct Draw {
+    uint32_t site;
+    int distinguished;
+    int seed;
+  };
+  std::vector<Draw> draws;
+  draws.reserve(3 * n);
+  for (size_t i = 0; i < n; ++i) {
     const int derivedAlleles = derivedAlleleCounts[i];
     const int totalSamples = totalSamplesCount[i];
     if (decodingUsesCSFS && numCsfsSamples > totalSamples) {
@@ -643,11 +871,41 @@ std::vector<std::vector<int>> Data::calculateUndistinguishedCounts(const int num
       throw std::runtime_error("Minor alleles has frequency > 50%. Data is supposed to be folded.");
     }
     for (int distinguished = 0; distinguished < 3; distinguished++) {
-      int sample = sampleHypergeometric(totalSamples - 2, derivedAlleles - distinguished, numCsfsSamples - 2);
+      const int successes = derivedAlleles - distinguished;
+      if (successes < 0 || successes > totalSamples - 2) {
+        undistinguished[i][static_cast<size_t>(distinguished)] = -1; // (no draw: Data.cpp:146-148)
+      } else {
+        draws.push_back(Draw{static_cast<uint32_t>(i), distinguished, std::rand()});
+      }
+    }
+  }
+  constexpr size_t kGrain = 64; // draws per task
+  parallelFor((draws.size() + kGrain - 1) / kGrain, [&](size_t task) {
+    std::vector<unsigned short> samplingVector;
+    const size_t lo = task * kGrain, hi = std::min(draws.size(), lo + kGrain);
+    for (size_t d = lo; d < hi; ++d) {
+      const Draw& dr = draws[d];
+      const int populationSize = totalSamplesCount[dr.site] - 2;
+      const int successes = derivedAlleleCounts[dr.site] - dr.distinguished;
+      const int sampleSizeCsfs = numCsfsSamples - 2;
+      samplingVector.assign(static_cast<size_t>(populationSize), 0);
+      for (int i = 0; i < successes; i++) {
+        samplingVector[static_cast<size_t>(i)] = 1;
+      }
+      std::shuffle(samplingVector.begin(), samplingVector.end(), std::mt19937(static_cast<unsigned>(dr.seed)));
+      int ret = 0;
+      for (int i = 0; i < sampleSizeCsfs; i++) {
+        ret += samplingVector[static_cast<size_t>(i)];
+      }
+      undistinguished[dr.site][static_cast<size_t>(dr.distinguished)] = ret;
+    }
+  });
+  for (size_t i = 0; i < n; ++i) {
+    for (int distinguished = 0; distinguished < 3; distinguished++) {
+      int& sample = undistinguished[i][static_cast<size_t>(distinguished)];
       if (foldToMinorAlleles && (sample + distinguished > numCsfsSamples / 2)) {
         sample = numCsfsSamples - 2 - sample;
       }
-      undistinguished[i][static_cast<size_t>(distinguished)] = sample;
     }
   }
   return undistinguished;

@@ -333,6 +333,9 @@ PYBIND11_MODULE(_pyasmc, m)
       .def_readwrite("w_j", &Data::w_j)
       .def_property_readonly("individuals", &Data::individuals,
                              "list of Individual (genotype1 / genotype2), unpacked from the bit matrix (Data.hpp:36)")
+      .def_readonly("globalIndIndex", &Data::globalIndIndex, "sample-file line of every loaded individual")
+      .def("calculateUndistinguishedCounts", &Data::calculateUndistinguishedCounts, "numCsfsSamples"_a,
+           "Data::calculateUndistinguishedCounts (Data.cpp:567-599): [sites][3]")
       .def("genotype", &Data::genotypeVector, "hapRow"_a, "folded genotype of haplotype row 2*ind + (hap-1)")
       .def("packed_bits", [](const Data& d) {
         return toArray<uint64_t>(d.bits, {static_cast<py::ssize_t>(d.numHapRows()), static_cast<py::ssize_t>(d.wordsPerHap)});

@@ -10,6 +10,7 @@ never as bench.py's `value`):
   short              the IBD decode alone on 60 000 hashing-style batches (32 pairs, 320-5504-site windows): the C5 regime
   identify           the identification step alone (fsmc_identify) on the C2 cohort (1000 x 50 000) and on a C3-shaped
                      one (10 000 x 100 000): pair-words/s of the three kernels, with the host restatement beside it
+  ingest_c3          host start-up at the C3 shape: Data(params) and HMM(data, params) on a 10 000 x 100 000 .hap.gz
 Prints one JSON object per measurement.  Usage: python tools/measure_configs.py [c1 k256 k192 k128 k100 hashing short identify]"""
 from __future__ import annotations
 
@@ -236,6 +237,82 @@ def run_c2(n_hap=1000, n_sites=50000):
                       "ibd_text_md5": hashlib.md5(txt).hexdigest()}))
 
 
+def ingest_c3(n_hap=10000, n_sites=100000):
+    """Host start-up at the C3 shape (10 000 haplotypes x 100 000 sites: 2 GB of haps text): Data(params) -- one
+    multi-threaded pass over the .hap.gz -- and HMM(data, params) -- emission preparation, 3 x sites shuffles of cohort
+    size -- timed separately, no GPU involved (the engine opens at the first decode)."""
+    import zlib
+
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(1234)
+    tables = synth.make_model_tables(69)
+    d = os.environ.get("FSMC_INGEST_DIR") or tempfile.mkdtemp()
+    root = os.path.join(d, "c3")
+    t0 = time.perf_counter()
+    bp = np.cumsum(rng.integers(1, 600, n_sites)).astype(np.int64)
+    cm = bp.astype(np.float64) * 1e-6
+    freq = np.minimum(0.5, 0.01 / rng.uniform(0.01, 0.5, n_sites))  # a folded 1/x spectrum, MAF >= 1 %
+    text_bytes = 0
+    with open(root + ".hap.gz", "wb") as f:
+        for s0 in range(0, n_sites, 500):  # one gzip member per 500 sites (a multi-member stream is a valid .gz)
+            n = min(500, n_sites - s0)
+            alleles = (rng.random((n, n_hap), dtype=np.float32) < freq[s0:s0 + n, None]).astype(np.uint8)
+            body = np.empty((n, 2 * n_hap + 1), np.uint8)
+            body[:, 0::2] = 32
+            body[:, 1::2] = alleles + 48
+            body[:, -1] = 10
+            out = bytearray()
+            for i in range(n):
+                out += f"1:{int(bp[s0 + i])}_A_G SNP{s0 + i} {int(bp[s0 + i])} A G".encode()
+                out += body[i].tobytes()
+            text_bytes += len(out)
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            f.write(co.compress(bytes(out)) + co.flush())
+    with open(root + ".samples", "w") as f:
+        f.write("ID_1 ID_2 missing\n0 0 0\n")
+        for i in range(n_hap // 2):
+            f.write(f"1_{i + 1} 1_{i + 1} 0\n")
+    with open(root + ".map", "w") as f:
+        for s in range(n_sites):
+            f.write(f"{int(bp[s])}\t1.0\t{float(cm[s])!r}\n")
+    gen = (cm / 100.0).astype(np.float32)
+    used = np.unique(np.concatenate([[0.0], O.step_rows(tables.keys, gen)[1][1:]]))
+    t = copy.copy(tables)
+    sel = np.nonzero(np.isin(t.keys, used.astype(np.float32)))[0]
+    t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
+    synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
+    t_write = time.perf_counter() - t0
+    p = api.DecodingParams()
+    p.inFileRoot = root
+    p.decodingQuantFile = root + ".decodingQuantities.gz"
+    p.outFileRoot = os.path.join(d, "out")
+    p.decodingModeString = "array"
+    p.foldData = True
+    p.usingCSFS = True
+    p.batchSize = 32
+    p.hashing = False
+    p.FastSMC = True
+    p.time = 50
+    p.useKnownSeed = True
+    res = {"config": "ingest_c3", "haplotypes": n_hap, "sites": n_sites, "haps_text_bytes": text_bytes,
+           "hap_gz_bytes": os.path.getsize(root + ".hap.gz"), "write_inputs_s": t_write,
+           "host_threads": int(os.environ.get("FSMC_HOST_THREADS", "0")) or min(16, os.cpu_count() or 1)}
+    t0 = time.perf_counter()
+    data = api.Data(p)
+    res["data_construct_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hmm = api.HMM(data, p)
+    res["hmm_construct_s"] = time.perf_counter() - t0
+    res["construct_s"] = res["data_construct_s"] + res["hmm_construct_s"]
+    res["sites_read"] = int(data.sites)
+    res["haps_text_GB_per_s"] = text_bytes / 1e9 / res["data_construct_s"]
+    del hmm
+    print(json.dumps(res), flush=True)
+    for ext in (".hap.gz", ".samples", ".map", ".decodingQuantities.gz"):
+        os.remove(root + ext)
+
+
 def short_windows():
     """The hashing regime (C5): batches of 32 pairs, each with its own short decode window (384-site median, as the
     C1 hashing run of SURVEY.md §0.9) -- pair-sites/s of the IBD decode alone."""
@@ -311,4 +388,5 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
         {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "hashing": hashing,
-         "short": short_windows, "run_c2": run_c2, "identify": identify, "seq": seq, "seq100": lambda: seq(100)}[w]()
+         "short": short_windows, "run_c2": run_c2, "ingest_c3": ingest_c3,
+         "ingest_small": lambda: ingest_c3(2000, 20000), "identify": identify, "seq": seq, "seq100": lambda: seq(100)}[w]()
