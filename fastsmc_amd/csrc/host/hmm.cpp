@@ -616,6 +616,9 @@ void HMM::flush()
     }
     check(mCtx, rc, "fsmc_decode_ibd_fetch");
     for (size_t i = 0; i < n; ++i) {
+      if (mKeepRecords) {
+        mKeptOrdinals.push_back(mPairsFlushed + recs[i].pair);
+      }
       writeIbd(mPairs[recs[i].pair], recs[i]);
     }
   }
@@ -690,6 +693,7 @@ void HMM::flush()
   // keep any pairs of a still-open batch
   std::vector<fsmc_pair> rest(mPairs.begin() + static_cast<long>(mBatchBegin), mPairs.end());
   mPairs.swap(rest);
+  mPairsFlushed += nPairs;
   mGroups.clear();
   mBatchFirstGroup.clear();
   mBatchBegin = 0;

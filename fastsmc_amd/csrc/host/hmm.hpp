@@ -148,6 +148,8 @@ public:
   void setKeepIbdRecords(bool v) { mKeepRecords = v; }
   const std::vector<fsmc_ibd_record>& getIbdRecords() const { return mKeptRecords; }
   const std::vector<fsmc_pair>& getIbdRecordPairs() const { return mKeptPairs; }
+  // ordinal of every kept record's pair among all the pairs this HMM has decoded (the candidate number in hashing mode)
+  const std::vector<uint64_t>& getIbdRecordOrdinals() const { return mKeptOrdinals; }
   unsigned long long getNumSegmentsDetected() const { return mSegmentsDetected; }
 
   // text of one IBD record, exactly as HMM::writePairIBD formats it (HMM.cpp:1116-1144)
@@ -197,6 +199,8 @@ private:
   bool mKeepRecords = false;
   std::vector<fsmc_ibd_record> mKeptRecords;
   std::vector<fsmc_pair> mKeptPairs;
+  std::vector<uint64_t> mKeptOrdinals;
+  uint64_t mPairsFlushed = 0; // pairs of the flushes before the current one
   std::vector<float> mExpectedCoalTimes;
 };
 

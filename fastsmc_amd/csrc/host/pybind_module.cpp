@@ -391,6 +391,40 @@ PYBIND11_MODULE(_pyasmc, m)
              }
              return out;
            })
+      .def("getIbdRecordArrays",
+           [](const HMM& h) {
+             // the kept records as columns (numpy): pair ordinal, hapA, hapB, start, end, prob, postMean, map
+             const auto& r = h.getIbdRecords();
+             const auto& p = h.getIbdRecordPairs();
+             const auto& o = h.getIbdRecordOrdinals();
+             const py::ssize_t n = static_cast<py::ssize_t>(r.size());
+             py::array_t<uint64_t> ord(n);
+             py::array_t<uint32_t> ha(n), hb(n);
+             py::array_t<int32_t> st(n), en(n);
+             py::array_t<float> pr(n), pm(n), mp(n);
+             for (py::ssize_t i = 0; i < n; ++i) {
+               const size_t k = static_cast<size_t>(i);
+               ord.mutable_at(i) = k < o.size() ? o[k] : 0;
+               ha.mutable_at(i) = p[k].hap_a;
+               hb.mutable_at(i) = p[k].hap_b;
+               st.mutable_at(i) = r[k].start;
+               en.mutable_at(i) = r[k].end;
+               pr.mutable_at(i) = r[k].prob;
+               pm.mutable_at(i) = r[k].post_mean;
+               mp.mutable_at(i) = r[k].map;
+             }
+             py::dict d;
+             d["pair"] = ord;
+             d["hap_a"] = ha;
+             d["hap_b"] = hb;
+             d["start"] = st;
+             d["end"] = en;
+             d["prob"] = pr;
+             d["post_mean"] = pm;
+             d["map"] = mp;
+             return d;
+           },
+           "the kept IBD records as numpy columns; `pair` = ordinal of the record's pair among all pairs decoded so far")
       .def("getIbdLines",
            [](const HMM& h) {
              std::string s;

@@ -314,6 +314,36 @@ def write_haps_files(root: str, h: SynthHaps, chrom: int = 1, fastsmc_map: bool 
                 f.write(f"{chrom}\tSNP_{int(h.bp[s])}\t{float(h.cm[s])!r}\t{int(h.bp[s])}\n")
 
 
+def write_haps_files_fast(root: str, h: SynthHaps, chrom: int = 1, block: int = 512) -> None:
+    """``write_haps_files`` (FastSMC-mode map) for big cohorts: the allele text is built with array operations, a block
+    of sites at a time, and every block is its own gzip member (a multi-member stream is a valid .gz) -- seconds
+    instead of minutes for 16 384 haplotypes x 20 000 sites."""
+    import zlib
+
+    n_hap, S = h.alleles.shape
+    with open(root + ".hap.gz", "wb") as f:
+        for s0 in range(0, S, block):
+            n = min(block, S - s0)
+            body = np.empty((n, 2 * n_hap + 1), np.uint8)
+            body[:, 0::2] = 32
+            body[:, 1:-1:2] = h.alleles[:, s0:s0 + n].T + 48
+            body[:, -1] = 10
+            out = bytearray()
+            for i in range(n):
+                b = int(h.bp[s0 + i])
+                out += f"{chrom}:{b}_1_2 SNP_{b} {b} 1 2".encode()
+                out += body[i].tobytes()
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            f.write(co.compress(bytes(out)) + co.flush())
+    with open(root + ".samples", "w") as f:
+        f.write("ID_1 ID_2 missing\n0 0 0\n")
+        for i in range(n_hap // 2):
+            f.write(f"1_{i + 1} 1_{i + 1} 0\n")
+    with open(root + ".map", "w") as f:
+        for s in range(S):
+            f.write(f"{int(h.bp[s])}\t0.0\t{float(h.cm[s])!r}\n")
+
+
 def cm_rate_placeholder(h: SynthHaps, s: int) -> float:
     """Second column of the FastSMC map (cM/Mb rate); read and ignored by Data.cpp:116-128."""
     if s == 0:

@@ -10,6 +10,7 @@ never as bench.py's `value`):
   short              the IBD decode alone on 60 000 hashing-style batches (32 pairs, 320-5504-site windows): the C5 regime
   identify           the identification step alone (fsmc_identify) on the C2 cohort (1000 x 50 000) and on a C3-shaped
                      one (10 000 x 100 000): pair-words/s of the three kernels, with the host restatement beside it
+  c5_job             one job window of a biobank-scale run: 16 384 haplotypes x 20 000 sites, hashing on, job 2 of 4
   ingest_c3          host start-up at the C3 shape: Data(params) and HMM(data, params) on a 10 000 x 100 000 .hap.gz
 Prints one JSON object per measurement.  Usage: python tools/measure_configs.py [c1 k256 k192 k128 k100 hashing short identify]"""
 from __future__ import annotations
@@ -313,6 +314,62 @@ def ingest_c3(n_hap=10000, n_sites=100000):
         os.remove(root + ext)
 
 
+def c5_job(n_ind=8192, n_sites=20000, jobs=4, job=2):
+    """One job of a biobank-scale run (BASELINE config 5): 16 384 haplotypes x 20 000 sites, hashing on, job 2 of 4 = the
+    off-diagonal square of 67 M pairs: FastSMC(params) construction (one-pass reader + emission preparation) and run()
+    (identification on the device, batching, paired windowed decode, binary output), timed."""
+    from oracle import oracle as O
+
+    haps = synth.make_haps_blocked(2 * n_ind, n_sites, seed=99, n_founders=48, cm_per_mb=1.0, switch_per_cm=0.3)
+    tables = synth.make_model_tables(69)
+    with tempfile.TemporaryDirectory() as d:
+        root = os.path.join(d, "c5")
+        synth.write_haps_files_fast(root, haps)
+        gen = (haps.cm / np.float32(100.0)).astype(np.float32)
+        used = np.unique(np.concatenate([[0.0], O.step_rows(tables.keys, gen)[1][1:]]))
+        t = copy.copy(tables)
+        sel = np.nonzero(np.isin(t.keys, used.astype(np.float32)))[0]
+        t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
+        synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
+        p = api.DecodingParams()
+        p.inFileRoot = root
+        p.decodingQuantFile = root + ".decodingQuantities.gz"
+        p.outFileRoot = os.path.join(d, "out")
+        p.decodingModeString = "array"
+        p.foldData = True
+        p.usingCSFS = True
+        p.batchSize = 32
+        p.min_m = 1.0
+        p.hashing = True
+        p.FastSMC = True
+        p.BIN_OUT = True
+        p.outputIbdSegmentLength = True
+        p.time = 50
+        p.noConditionalAgeEstimates = True
+        p.doPerPairMAP = True
+        p.doPerPairPosteriorMean = True
+        p.useKnownSeed = True
+        p.jobs, p.jobInd = jobs, job
+        assert p.validateParamsFastSMC()
+        t0 = time.perf_counter()
+        f = api.FastSMC(p)
+        t_init = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        f.run()
+        t_run = time.perf_counter() - t0
+        segs = int(f.hmm().getNumSegmentsDetected())
+        t0 = time.perf_counter()
+        cands = api.hashingCandidatesDevice(api.Data(p), p)
+        t_ident = time.perf_counter() - t0
+        size = os.path.getsize(f.outputFileName())
+    w = np.array([c[3] - c[2] for c in cands], np.int64)
+    print(json.dumps({"config": "c5_job_window", "haplotypes": 2 * n_ind, "sites": n_sites, "jobs": jobs, "jobInd": job,
+                      "pairs_in_window": (n_ind // 2) * (n_ind // 2) * 4, "candidates": len(cands),
+                      "candidate_sites_median": float(np.median(w)), "candidate_pair_sites": int(w.sum()),
+                      "segments": segs, "construct_s": t_init, "run_s": t_run,
+                      "reread_plus_identify_s": t_ident, "bibd_bytes": size}), flush=True)
+
+
 def short_windows():
     """The hashing regime (C5): batches of 32 pairs, each with its own short decode window (384-site median, as the
     C1 hashing run of SURVEY.md §0.9) -- pair-sites/s of the IBD decode alone."""
@@ -388,5 +445,5 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
         {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "hashing": hashing,
-         "short": short_windows, "run_c2": run_c2, "ingest_c3": ingest_c3,
+         "short": short_windows, "run_c2": run_c2, "ingest_c3": ingest_c3, "c5_job": c5_job,
          "ingest_small": lambda: ingest_c3(2000, 20000), "identify": identify, "seq": seq, "seq100": lambda: seq(100)}[w]()
