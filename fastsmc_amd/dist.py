@@ -141,3 +141,40 @@ def run_fastsmc_sharded(params, rank: int | None = None, world: int | None = Non
                 os.remove(name)
     barrier()
     return final
+
+
+IBD_COLUMNS = (("pair", np.uint64), ("hap_a", np.uint32), ("hap_b", np.uint32), ("start", np.int32), ("end", np.int32),
+               ("prob", np.float32), ("post_mean", np.float32), ("map", np.float32))
+IBD_ROW_DTYPE = np.dtype([(n, np.dtype(t).newbyteorder("<")) for n, t in IBD_COLUMNS])
+
+
+def gather_hmm_records(hmm, dist=None, rank: int = 0, world: int = 1, device="cpu"):
+    """The in-memory counterpart of ``run_fastsmc_sharded``'s part files: every rank's kept IBD records
+    (``HMM.setKeepIbdRecords(True)``; ``HMM.getIbdRecordArrays()``) gathered to rank 0 over the process group -- RCCL over
+    xGMI with backend "nccl" and ``device="cuda"``, gloo in CPU tests -- as one structured array (``IBD_ROW_DTYPE``).
+    Shards are contiguous ranges of the job's batches and each rank's records are in output order, so the
+    concatenation in rank order IS the single-GPU record stream (``pair`` = the record's pair ordinal within its rank's
+    shard).  Returns (total_count, records on rank 0 / None elsewhere).  The only collective of the path: an all_gather
+    of the counts and one gather of padded payloads."""
+    cols = hmm.getIbdRecordArrays()
+    local = np.zeros(cols["pair"].size, IBD_ROW_DTYPE)
+    for name, _ in IBD_COLUMNS:
+        local[name] = cols[name]
+    if dist is None or world == 1:
+        return int(local.size), local
+    import torch
+
+    cnt = torch.tensor([local.size], device=device, dtype=torch.int64)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    item = IBD_ROW_DTYPE.itemsize
+    payload = torch.zeros(max(max(counts), 1) * item, dtype=torch.uint8, device=device)
+    if local.size:
+        payload[: local.nbytes] = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(device)
+    bucket = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+    dist.gather(payload, bucket, dst=0)
+    if rank != 0:
+        return sum(counts), None
+    parts = [bucket[r][: counts[r] * item].cpu().numpy().view(IBD_ROW_DTYPE) for r in range(world)]
+    return sum(counts), np.concatenate(parts)

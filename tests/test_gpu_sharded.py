@@ -58,3 +58,26 @@ def test_sharded_two_processes(files, tmp_path):
         pr.join(600)
         assert pr.exitcode == 0
     assert gzip.open(out + ".1.1.FastSMC.ibd.gz", "rb").read() == want
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hashing=True, min_m=1.0)], ids=["all-pairs", "hashing"])
+def test_in_memory_records_of_the_shards_are_the_single_device_stream(files, tmp_path, kw):
+    """The in-memory consumer (HMM.getIbdRecordArrays + dist.gather_hmm_records, the RCCL gather of the product): the
+    shards' kept records, in rank order, are the records of the one-device run -- every field, every bit."""
+    import numpy as np
+
+    def records(rank, world):
+        f = api.FastSMC(_params(files, str(tmp_path / f"m{rank}of{world}"), **kw))
+        f.setShard(rank, world)
+        f.hmm().setKeepIbdRecords(True)
+        f.run()
+        return dist.gather_hmm_records(f.hmm())[1]
+
+    one = records(0, 1)
+    assert one.size > 20
+    parts = [records(r, 3) for r in range(3)]
+    merged = np.concatenate(parts)
+    for name in one.dtype.names:
+        if name != "pair":  # (ordinals count from the start of each rank's shard)
+            np.testing.assert_array_equal(merged[name], one[name], err_msg=name)
+    assert all((np.diff(p["pair"].astype(np.int64)) >= 0).all() for p in parts)

@@ -147,3 +147,58 @@ def test_strong_scaling_list_world_size_2(tmp_path):
         want.append(rec)
     want = np.concatenate(want)
     assert np.array_equal(merged, want) and np.all(np.diff(merged["pair"].astype(np.int64)) >= 0)
+
+
+# the product's in-memory gather (fastsmc_amd.dist.gather_hmm_records): the record columns an HMM keeps, world 2, gloo
+class _FakeHmm:
+    def __init__(self, rec):
+        self._rec = rec
+
+    def getIbdRecordArrays(self):
+        return {n: self._rec[n] for n in self._rec.dtype.names}
+
+
+def _fake_rows(n, seed):
+    from fastsmc_amd.dist import IBD_ROW_DTYPE
+
+    rng = np.random.default_rng(seed)
+    rec = np.zeros(n, IBD_ROW_DTYPE)
+    rec["pair"] = np.sort(rng.integers(0, 500, size=n))
+    rec["hap_a"], rec["hap_b"] = rng.integers(0, 64, size=n), rng.integers(64, 128, size=n)
+    rec["start"] = rng.integers(0, 1000, size=n)
+    rec["end"] = rec["start"] + rng.integers(0, 50, size=n)
+    rec["prob"], rec["post_mean"], rec["map"] = rng.random(n), rng.random(n) * 100, rng.random(n) * 100
+    return rec
+
+
+def _hmm_worker(rank, world, port, out_path):
+    from fastsmc_amd.dist import gather_hmm_records
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, merged = gather_hmm_records(_FakeHmm(_fake_rows(37 if rank == 0 else 0 if rank == 1 else 11, 7 + rank)), dist,
+                                       rank, world)
+    if rank == 0:
+        np.save(out_path, merged)
+        assert total == merged.size
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hmm_record_gather_world_size_3_with_an_empty_rank(tmp_path):
+    from fastsmc_amd.dist import gather_hmm_records
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rows.npy")
+    mp.spawn(_hmm_worker, args=(3, port, out), nprocs=3, join=True)
+    merged = np.load(out)
+    want = np.concatenate([_fake_rows(37, 7), _fake_rows(0, 8), _fake_rows(11, 9)])
+    assert merged.dtype == want.dtype and np.array_equal(merged, want)
+    # one process: the records as they are
+    total, alone = gather_hmm_records(_FakeHmm(_fake_rows(5, 1)))
+    assert total == 5 and np.array_equal(alone, _fake_rows(5, 1))

@@ -23,7 +23,17 @@ for f in glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "decode_kernel" in r.get("Kernel_Name",""):
             tot[r["Counter_Name"]]+=float(r["Counter_Value"])
+import sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+from fastsmc_amd.build import hip_source_hash
 with open(out+"/summary.txt","w") as w:
+    w.write(f"lib_hash\t{hip_source_hash()}\n")
+    w.write("bench_args\t$*\n")
+    names=set()
+    for f in glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "decode_kernel" in r.get("Kernel_Name",""): names.add(r["Kernel_Name"])
+    for n in sorted(names): w.write(f"kernel\t{n}\n")
     for k in sorted(tot): w.write(f"{k}\t{tot[k]:.6g}\n")
     for f in glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True):
         w.write(open(f).read())

@@ -4,6 +4,7 @@
   tools/stamp_profiles.py traffic <profile_dir> <tag>   tools/profile_bench.sh output -> profiles/<tag>_traffic.json,
                                                          <tag>_kernel_stats.csv, <tag>_rocprofv3_summary.json
   tools/stamp_profiles.py c3n1 <bench_json> <tag>       `bench.py --workload c3` line -> profiles/<tag>_c3_n1.json
+  tools/stamp_profiles.py pmc <prof_dir> <name>         tools/prof_counters.sh output -> profiles/<name>.txt (stamped)
   tools/stamp_profiles.py round <round_dir> <tag>       tools/measure_round.sh output (gpurun_out/round_<tag>, with the C4
                                                          profile in gpurun_out/profile_<tag>_c4) -> profiles/<tag>_*
 
@@ -93,5 +94,15 @@ def round_files(src: str, tag: str) -> None:
     c3n1(os.path.join(src, "c3_n1.json"), tag)
 
 
+def pmc(src: str, name: str) -> None:
+    """tools/prof_counters.sh output (gpurun_out/prof_<tag>/summary.txt) -> profiles/<name>.txt; refused unless the
+    summary carries the hash of the library as it is now."""
+    txt = open(os.path.join(src, "summary.txt")).read()
+    first = txt.splitlines()[0].split("\t")
+    assert first[0] == "lib_hash" and first[1] == hip_source_hash(), "counters of another build of the library (or unstamped)"
+    open(os.path.join(ROOT, "profiles", f"{name}.txt"), "w").write(txt)
+    print(f"profiles/{name}.txt")
+
+
 if __name__ == "__main__":
-    {"traffic": traffic, "c3n1": c3n1, "round": round_files}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {"traffic": traffic, "c3n1": c3n1, "round": round_files, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
