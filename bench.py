@@ -162,6 +162,9 @@ def main() -> None:
     ap.add_argument("--diag-same-row", action="store_true",
                     help="diagnostic, NOT a result: every site uses the same transition-table row (scalar-cache hits)")
     ap.add_argument("--ws-frac", type=float, default=0.0, help="workspace cap as a fraction of HBM (0 = default)")
+    ap.add_argument("--resident-chunks", type=int, default=-1,
+                    help="chunks of a chunked window whose beta rows stay in the workspace (no rebuild): -1 = as many "
+                         "as memory allows, 0 = none")
     ap.add_argument("--cpu-pairs", type=int, default=-1,
                     help="pairs in the cpu_baseline sample (0 = skip, -1 = automatic: 128 per host core)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -237,6 +240,8 @@ def main() -> None:
         ctx.set_workspace_limit(int(args.ws_frac * ctx.info()["hbm_bytes"]))
     if args.beta_stride:
         ctx.set_beta_stride(args.beta_stride)
+    if args.resident_chunks >= 0:
+        ctx.set_resident_chunks(args.resident_chunks)
     flags = (capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP) if args.flags < 0 else args.flags
 
     def step():
@@ -290,6 +295,7 @@ def main() -> None:
                        "pair_sites_per_s": value * pm.S, "ibd_records_per_step": n_rec,
                        "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
                        "chunk_sites": info["chunk_sites"], "chunks_per_window": info["max_chunks"],
+                       "resident_chunks": ctx.last_resident_chunks(),
                        "beta_stride": ctx.last_beta_stride(), "kernel_member": ctx.last_kernel(),
                        "lib_hash": lib_hash(),
                        **({"kernel_ms_per_rank": per_rank_ms,

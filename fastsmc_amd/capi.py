@@ -27,7 +27,8 @@ FSMC_EOVERFLOW = -6
 SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
     "fsmc_ctx_set_chunk_sites", "fsmc_ctx_set_beta_stride", "fsmc_ctx_last_beta_stride", "fsmc_ctx_last_plan",
-    "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items",
+    "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items", "fsmc_ctx_set_resident_chunks",
+    "fsmc_ctx_last_resident_chunks",
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
     "fsmc_decode_ibd",
@@ -175,6 +176,15 @@ class Context:
 
     def set_chunk_sites(self, sites: int):
         self._check(self._L.fsmc_ctx_set_chunk_sites(self._h, sites))
+
+    def set_resident_chunks(self, chunks: int):
+        """-1 = as many of a chunked window's first chunks as memory allows keep their rows (no rebuild), 0 = none."""
+        self._check(self._L.fsmc_ctx_set_resident_chunks(self._h, chunks))
+
+    def last_resident_chunks(self) -> int:
+        v = C.c_int32(0)
+        self._check(self._L.fsmc_ctx_last_resident_chunks(self._h, C.byref(v)))
+        return v.value
 
     def set_beta_stride(self, stride: int):
         """0 = automatic, 1 = every beta row through HBM, 2 = every second row (the others recomputed)."""

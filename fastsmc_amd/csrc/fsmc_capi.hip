@@ -84,7 +84,8 @@ struct fsmc_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int lastSlots = 0;
-  int lastChunk = 0, lastMaxChunks = 0;
+  int lastChunk = 0, lastMaxChunks = 0, lastResident = 0;
+  int residentChunks = -1; // chunks of a window that skip the rebuild: -1 = as many as the workspace limit allows, 0 = none
   uint32_t chunkSites = 0; // 0 = automatic
   uint32_t betaStride = 0; // 0 = automatic (2 where the kernel exists), 1 = store every beta row
   int lastStride = 1;
@@ -366,6 +367,7 @@ struct LaunchPlan {
   int chunk = 0;
   int chunkRows = 0; // rows of the chunk buffer (chunk, or half of it with beta stride 2)
   int maxChunks = 0;
+  int residentChunks = 0; // chunk buffers beyond the first: chunks whose rows pass B keeps (no rebuild)
   size_t wsSlot = 0; // float4 per slot
   int slots = 0;
 };
@@ -414,11 +416,11 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / share;
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
   const bool half = halfAvailable(mode, m) && ctx->betaStride != 1;
-  (void)paired;
   auto chunkRows = [&](size_t c) { return half ? (c + 1) / 2 : c; };
   const size_t rowsAvail = (size_t)(limit / (vecBytes * slots)); // rows one resident wave may hold
   size_t C, maxChunks;
-  if (chunkRows(L) + 5 <= rowsAvail) {
+  // (an explicit chunk length is kept, except for paired launches, which only have the single-chunk layout)
+  if (chunkRows(L) + 5 <= rowsAvail && !(ctx->chunkSites && ctx->chunkSites < L && !paired)) {
     C = L;
     maxChunks = 1;
   } else {
@@ -439,13 +441,43 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
       return fail(ctx, FSMC_ENOMEM, "workspace limit too small for the decode window");
     }
   }
+  // Resident chunks (fsmc_kernels.h): a chunked window rebuilds every chunk's rows from a checkpoint -- one of its 3.5
+  // sweeps -- except for the chunks whose rows pass B can leave in the workspace.  Whatever the limit leaves after the
+  // one chunk buffer, the checkpoints and the parking rows goes to such chunks (array-mode IBD decode of the
+  // lane-per-pair family; paired launches are single-chunk).
+  size_t resident = 0;
+  if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && ctx->residentChunks != 0) {
+    // (their budget: the caller's limit if one is set; otherwise up to 80 % of the card where that much is free -- the
+    //  card has 288 GB and the model, the haplotypes and the records are small -- but never less than the plan's own)
+    uint64_t budget = limit;
+    if (!ctx->wsLimit) {
+      size_t freeB = 0, totalB = 0;
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        const DevBuf& cur = ws ? *ws : ctx->ws;
+        const uint64_t reachable = (uint64_t)freeB + cur.bytes;
+        const uint64_t margin = (uint64_t)(0.04 * (double)ctx->hbmBytes);
+        const uint64_t want = (uint64_t)(0.80 * (double)ctx->hbmBytes) / share;
+        budget = std::max<uint64_t>(limit, std::min<uint64_t>(want, reachable > margin ? reachable - margin : 0));
+      }
+    }
+    const size_t rowsBudget = (size_t)(budget / (vecBytes * slots));
+    const size_t fixed = chunkRows(C) + maxChunks + 5;
+    if (rowsBudget > fixed) {
+      resident = std::min<size_t>((rowsBudget - fixed) / chunkRows(C), maxChunks);
+      if (ctx->residentChunks > 0) {
+        resident = std::min<size_t>(resident, (size_t)ctx->residentChunks);
+      }
+    }
+  }
   plan.chunk = (int)C;
   plan.chunkRows = (int)chunkRows(C);
   plan.maxChunks = (int)maxChunks;
-  plan.wsSlot = (chunkRows(C) + maxChunks + 2 + 2) * K4 * kWave;
+  plan.residentChunks = (int)resident;
+  plan.wsSlot = (chunkRows(C) * (1 + resident) + maxChunks + 2 + 2) * K4 * kWave;
   plan.slots = (int)slots;
   ctx->lastChunk = plan.chunk;
   ctx->lastMaxChunks = plan.maxChunks;
+  ctx->lastResident = plan.residentChunks;
   return ensure(ctx, ws ? *ws : ctx->ws, plan.wsSlot * sizeof(float4) * slots);
 }
 
@@ -494,6 +526,7 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.chunk = plan.chunk;
   p.chunkRows = plan.chunkRows;
   p.maxChunks = plan.maxChunks;
+  p.residentChunks = plan.residentChunks;
   p.flags = flags;
   p.pi = m->pi;
   p.cR = m->cR;
@@ -743,6 +776,24 @@ int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_c
   if (chunk_sites) *chunk_sites = ctx->lastChunk;
   if (max_chunks) *max_chunks = ctx->lastMaxChunks;
   if (n_slots) *n_slots = ctx->lastSlots;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_set_resident_chunks(fsmc_ctx* ctx, int32_t chunks)
+{
+  if (!ctx || chunks < -1) {
+    return fail(ctx, FSMC_EINVAL, "resident chunks: -1 (automatic), 0 (none) or a count");
+  }
+  ctx->residentChunks = chunks;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_last_resident_chunks(const fsmc_ctx* ctx, int32_t* chunks)
+{
+  if (!ctx || !chunks) {
+    return FSMC_EINVAL;
+  }
+  *chunks = ctx->lastResident;
   return FSMC_OK;
 }
 

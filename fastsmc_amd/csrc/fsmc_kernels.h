@@ -86,6 +86,8 @@ struct KParams {
   float* sums;                // kModeSums: one plane [S][K] (x4 with the 00/01/11 sums) per wave of the launch
   size_t sumsPlane;           // floats per plane per slot
   const unsigned* batchFirst; // kModeSums: [nBatches + 1] first group of every batch (null: every group is a batch)
+  int residentChunks;         // chunked windows, array mode: the first this-many chunks of a window keep the rows pass B
+                              // computes for them (a chunk buffer each) and skip the rebuild pass
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1041,6 +1043,14 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   float4* const ckpt = chunkbuf + (size_t)p.chunkRows * vecF4;
   float4* const saveA = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
   float4* const saveS = saveA + vecF4;
+  // Resident chunks (multi-chunk windows, array mode): pass B walks down to the window's first site, so the rows of the
+  // window's FIRST chunks are the last it computes -- where the workspace has room (288 GB of HBM: the host plans up to
+  // p.residentChunks extra chunk buffers per wave) pass B keeps them and pass A sweeps those chunks without rebuilding
+  // them: the same rows, bit for bit (the rebuild repeats pass B's operations on the same operands).
+  float4* const resBase = saveS + vecF4;
+  // (array-mode IBD decode, one group per wave: paired launches are single-chunk by construction)
+  constexpr bool kResidentBuilt = !SEQ && !DUAL && MODE == kModeIbd;
+  const int nResident = kResidentBuilt ? p.residentChunks : 0;
   const int C = p.chunk;
   // per-state posterior sums of the open segments (TRACK), one column per lane
   float4* const spsMem = saveS + threadIdx.x;
@@ -1272,11 +1282,24 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             store_vec<KT, KA>(K, chunkbuf + slotOf(rel) * vecF4, laneOff, b);
             return true;
           }
-        } else if (__builtin_expect(pos == ckPos && ckJ >= 1, 0)) { // once per chunk
-          store_vec<KT, KA>(K, ckpt + (size_t)ckJ * vecF4, laneOff, b);
-          ckJ -= 1;
-          ckPos = from + ckJ * C;
-          return true;
+        } else {
+          bool out = false;
+          // (pos lies in chunk ckJ: the checkpoint countdown below IS the chunk pass B is in)
+          if (kResidentBuilt && ckJ < nResident && pos < aEnd) { // a resident chunk: the row stays, at its chunk-local slot
+            const int relc = pos - ckPos;
+            const int hiJ = ckPos + C < aEnd ? ckPos + C : aEnd;
+            if (!HALF || (relc & 1) || pos == hiJ - 1) {
+              store_vec<KT, KA>(K, resBase + ((size_t)ckJ * p.chunkRows + slotOf(relc)) * vecF4, laneOff, b);
+              out = true;
+            }
+          }
+          if (__builtin_expect(pos == ckPos && ckJ >= 1, 0)) { // once per chunk
+            store_vec<KT, KA>(K, ckpt + (size_t)ckJ * vecF4, laneOff, b);
+            ckJ -= 1;
+            ckPos = from + ckJ * C;
+            out = true;
+          }
+          return out;
         }
         return false;
       };
@@ -1406,7 +1429,10 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
     for (int j = 0; j < (nChunks > 0 ? nChunks : 0); ++j) {
       const int lo = from + j * C;
       const int hi = (lo + C < aEnd) ? lo + C : aEnd;
-      if (!single) {
+      // the rows of this chunk: kept by pass B (a resident chunk), or rebuilt below into the wave's chunk buffer
+      const bool resident = kResidentBuilt && !single && j < nResident;
+      float4* const cbuf = resident ? resBase + (size_t)j * p.chunkRows * vecF4 : chunkbuf;
+      if (!single && !resident) {
         // park the carried alpha while the chunk's betas are rebuilt
         if (j > 0) {
           store_vec<KT, KA>(K, saveA, laneOff, a);
@@ -1516,7 +1542,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
       // the wave's own stores of this chunk's betas must have landed before the DMA reads them back
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       waitVm0();
-      fetchBeta(chunkbuf);
+      fetchBeta(cbuf);
       EmisRegs ev;
       if constexpr (SEQ) {
         ev = prefetchEmis(lo);
@@ -1694,7 +1720,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
         // every read of the landing zone has returned: request the next site's beta row
         waitLgkm0();
         if (MODE != kModeSums && !rec && pos + 1 < hi) {
-          fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4);
+          fetchBeta(cbuf + slotOf(pos + 1 - lo) * vecF4);
         }
         if constexpr (!SEQ && MODE != kModeSums) {
           if (pos + 2 < hi) {
@@ -1777,7 +1803,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
           waitLgkm0();
           __builtin_amdgcn_wave_barrier();
           if (pos + 1 < hi) {
-            fetchBeta(chunkbuf + slotOf(pos + 1 - lo) * vecF4);
+            fetchBeta(cbuf + slotOf(pos + 1 - lo) * vecF4);
           }
           if constexpr (!SEQ) {
             if (pos + 2 < hi) {

@@ -135,6 +135,12 @@ int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
 /* How the last launch was laid out: sites per chunk (= the longest window when every beta row fitted), chunks per
  * window, resident waves. */
 int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_chunks, int32_t* n_slots);
+/* Chunked windows (longer than a wave's workspace holds) rebuild every chunk's beta rows from a checkpoint -- one of the
+ * decode's 3.5 sweeps -- except for the window's first chunks, whose rows the backward pass can leave in the workspace
+ * ("resident chunks").  chunks = -1 (default): as many as memory allows -- the workspace limit if one is set, otherwise up
+ * to 80 % of the card where that much is free; 0: none; n: at most n.  Results do not depend on it. */
+int fsmc_ctx_set_resident_chunks(fsmc_ctx* ctx, int32_t chunks);
+int fsmc_ctx_last_resident_chunks(const fsmc_ctx* ctx, int32_t* chunks);
 /* Two half-groups per wavefront.  A group of at most 32 pairs (a hashing-mode batch of the reference's default size)
  * fills half a wave; with pairing = 1 (default) the IBD decode puts two such groups with nearby windows on one wave,
  * each lane still decoded over its own group's windows (results do not depend on it); half-full groups that find no

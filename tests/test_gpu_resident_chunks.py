@@ -1,0 +1,59 @@
+"""Resident chunks (fsmc_ctx_set_resident_chunks): in a chunked window the backward pass leaves the beta rows of the
+window's first chunks in the workspace, and the forward sweep of those chunks skips the rebuild pass.  The rows are the
+ones the rebuild would produce -- the same operations on the same operands -- so the records must not depend on how many
+chunks are resident: 0, 1, 2, all of them; beta stride 1 and 2; with and without segment ages; windows whose scan ends
+inside a chunk; against the oracle bit for bit."""
+import numpy as np
+import pytest
+
+from fastsmc_amd import capi
+from oracle import oracle as O
+from test_gpu_beta_stride import FIELDS, _assert_records_equal, _ctx, _pairs_array, _window_oracle
+
+pytestmark = pytest.mark.gpu
+
+WINS = [  # first pair, pairs, from, to, scan_from, scan_to
+    (0, 64, 0, 640, 0, 640), (64, 40, 3, 636, 3, 636), (104, 64, 10, 331, 37, 300), (168, 9, 100, 101, 100, 101),
+    (177, 33, 200, 202, 200, 202), (210, 64, 300, 303, 301, 303), (274, 64, 5, 422, 6, 421), (338, 20, 0, 49, 0, 49),
+    (358, 64, 590, 640, 601, 640), (422, 64, 0, 640, 100, 333),
+]
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("flags", [capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP, 0])
+def test_records_do_not_depend_on_resident_chunks(small_problem, stride, flags):
+    pm = small_problem["model"]
+    n = WINS[-1][0] + WINS[-1][1]
+    pairs = O.enumerate_all_pairs(32)[500:500 + n]
+    groups = np.zeros(len(WINS), capi.GROUP_DTYPE)
+    for g, w in zip(groups, WINS):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    res = {}
+    for resident in (0, 1, 2, -1):
+        ctx, model = _ctx(small_problem, stride, limit=(1 << 30) if resident < 0 else (64 << 20), chunk=48)
+        ctx.set_resident_chunks(resident)
+        res[resident] = ctx.decode_ibd(model, _pairs_array(pairs), groups, flags)
+        info = ctx.info()
+        assert info["max_chunks"] > 10  # the 640-site windows are chunked
+        got_resident = ctx.last_resident_chunks()
+        assert got_resident == (resident if resident >= 0 else info["max_chunks"])
+        ctx.close()
+    for r in (1, 2, -1):
+        assert res[r].tobytes() == res[0].tobytes(), f"resident = {r}"
+    want = []
+    for first, cnt, frm, to, sfrm, sto in WINS:
+        full = _window_oracle(small_problem, pairs[first:first + cnt], frm, to, sfrm, sto)
+        for v in range(cnt):
+            want.append(O.ibd_scan_pair(pm, full, v, sfrm, sto, pair_ordinal=first + v,
+                                        want_mean=bool(flags & capi.FSMC_WANT_MEAN),
+                                        want_map=bool(flags & capi.FSMC_WANT_MAP)))
+    want = np.concatenate(want)
+    assert want.size > 20
+    _assert_records_equal(res[-1], want)
+
+
+def test_resident_chunks_setting_is_validated(small_problem):
+    ctx = capi.Context(0)
+    with pytest.raises(capi.FsmcError):
+        ctx.set_resident_chunks(-2)
+    ctx.close()
