@@ -424,11 +424,13 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     C = L;
     maxChunks = 1;
   } else {
-    // A window no longer than a chunk skips the rebuild pass (single-chunk layout), and chunk length costs nothing
-    // else, so the default is generous: 2048 sites (the hashing pre-filter's windows are a few hundred) or
-    // sqrt(window) if that is larger, shrunk to what the workspace limit allows.
+    // The chunk length of a window that does not fit the workspace whole: 512 sites, or sqrt(window) if that is larger
+    // (memory is chunk + window / chunk rows), shrunk to what the workspace limit allows.  Short chunks cost a
+    // checkpoint row and a pipeline restart each and let the resident chunks (below) fill the memory that is left to
+    // the last row: C2 at 2048 / 1024 / 512 sites a chunk runs 1886 / 1881 / 1870 ms.
     C = ctx->chunkSites ? (size_t)ctx->chunkSites
-                        : std::max<size_t>((size_t)std::ceil(std::sqrt((double)L)), 2048);
+                        : std::max<size_t>((size_t)std::ceil(std::sqrt((double)L)), w2 ? 2048 : 512);
+    // (the wave-group kernel has no resident chunks and pays more per restart: 2048)
     C = std::min((C + 15) / 16 * 16, (L + 15) / 16 * 16);
     auto fits = [&](size_t c) { return chunkRows(c) + (L + c - 1) / c + 5 <= rowsAvail; };
     if (!ctx->chunkSites) {
