@@ -959,6 +959,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
             const int q = pos + 1;
             waitEmisRows(stored);
             __builtin_amdgcn_wave_barrier();
+            FSMC_END(cycW, 29);
             if (pos - 1 >= from) {
               stageEmis(q - 1);
             }
@@ -1040,6 +1041,7 @@ __global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KPara
             const int q = pos + 1;
             waitEmisRows(stored);
             __builtin_amdgcn_wave_barrier();
+            FSMC_END(cycW, 29); // (diagnostic split of region 20: loop control + the wait for the emission rows)
             if (pos - 1 >= lo) {
               stageEmis(q - 1);
             }

@@ -9,7 +9,7 @@ NAMES = {0: "b.ph0 work", 1: "b.ph1 work", 2: "b.ph2 work", 3: "b.ph3 work", 4: 
          12: "a.ph2 work", 13: "a.ph3 work", 14: "a.ph0 barrier", 15: "a.ph1 barrier", 16: "a.ph2 barrier",
          17: "a.ph3 barrier", 18: "a.sum", 19: "a.scale", 20: "between b steps", 21: "in front of a step",
          22: "combine", 23: "combine sum", 24: "consumer rest", 25: "next-row requests", 26: "scan sum",
-         27: "scan decision", 28: "scan barrier", 29: "-"}
+         27: "scan decision", 28: "scan barrier", 29: "b loop: wait for emission rows"}
 d = json.load(open(sys.argv[1]))
 pc = d["config"]["phase_cycles"]
 tot = [sum(pc[8 + 30 * h:8 + 30 * h + 30]) for h in range(4)]

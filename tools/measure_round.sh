@@ -30,5 +30,9 @@ python3 tools/measure_configs.py k256 k192 > $OUT/wide_w2.jsonl 2> $OUT/wide_w2.
 echo "identify done"
 python3 tools/measure_configs.py run_c2 > $OUT/run_c2.json 2> $OUT/run_c2.err
 python3 tools/measure_configs.py c1 > $OUT/c1.json 2> $OUT/c1.err
+python3 bench.py --workload c1 --steps 10 --warmup 2 --cpu-pairs 0 > $OUT/c1_bench.json 2> $OUT/c1_bench.err
+python3 tools/measure_configs.py c5_job > $OUT/c5_job.json 2> $OUT/c5_job.err
+python3 tools/measure_configs.py ingest_c3 > $OUT/ingest_c3.json 2> $OUT/ingest_c3.err
+echo "host done"
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "all done"

@@ -20,7 +20,7 @@ FIELDS = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scrat
 
 
 def demangle(names):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True)
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
     return out.stdout.strip().split("\n")
 
 

@@ -89,8 +89,10 @@ def round_files(src: str, tag: str) -> None:
                  ("c1.json", "c1_shape.jsonl"), ("identify.jsonl", "identify.jsonl"),
                  ("identify_kernel_stats.csv", "identify_kernel_stats.csv"),
                  ("hashing.json", "hashing_c2_files_end_to_end.json"), ("sequence.jsonl", "sequence_mode.jsonl"),
-                 ("wide_w2.jsonl", "wide_four_waves_per_group.jsonl")):
-        shutil.copy(os.path.join(src, a), os.path.join(prof, f"{tag}_{b}"))
+                 ("wide_w2.jsonl", "wide_four_waves_per_group.jsonl"), ("c1_bench.json", "c1_bench_line.json"),
+                 ("c5_job.json", "c5_job_window.json"), ("ingest_c3.json", "ingest_c3.json")):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copy(os.path.join(src, a), os.path.join(prof, f"{tag}_{b}"))
     c3n1(os.path.join(src, "c3_n1.json"), tag)
 
 
