@@ -19,11 +19,11 @@ gcc $SAN -std=c99 -c oracle/hmm_oracle.c -o $TMP/hmm_oracle.o
 g++ $SAN -std=c++17 -c oracle/undist_counts.cpp -o $TMP/undist.o
 g++ -shared -fsanitize=address,undefined -o oracle/liboracle.so $TMP/hmm_oracle.o $TMP/undist.o -lm
 PIDS=""
-for f in decoding_quantities decoding_params data hmm hashing drivers pybind_module; do
+for f in decoding_quantities decoding_params data hmm hashing drivers pybind_module pybind_containers; do
   g++ $SAN -std=c++17 -fvisibility=hidden -I $PBINC -I $PYINC -c fastsmc_amd/csrc/host/$f.cpp -o $TMP/$f.o & PIDS="$PIDS $!"
 done
 for P in $PIDS; do wait $P; done
 g++ -shared -fsanitize=address,undefined -o $MOD $TMP/decoding_quantities.o $TMP/decoding_params.o $TMP/data.o $TMP/hmm.o \
-    $TMP/hashing.o $TMP/drivers.o $TMP/pybind_module.o -L fastsmc_amd -lfastsmc_hip -lz -Wl,-rpath,'$ORIGIN'
+    $TMP/hashing.o $TMP/drivers.o $TMP/pybind_module.o $TMP/pybind_containers.o -L fastsmc_amd -lfastsmc_hip -lz -Wl,-rpath,'$ORIGIN'
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
   python -m pytest tests -x -q -m "not gpu" -k "not isa_hazards and not multiproc"
