@@ -52,7 +52,7 @@ def hip_source_hash() -> str:
 
 def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
     """hipcc cross-compiles the gfx950 code objects without a GPU: fsmc_capi.hip (host side + kernel selection),
-    fsmc_identify_sort.hip (rocPRIM sort of the identification step's candidates) and fsmc_inst.hip once per family member, in parallel, linked into one shared library."""
+    fsmc_identify_sort.hip and fsmc_identify_seeds.hip (rocPRIM sorts of the identification step) and fsmc_inst.hip once per family member, in parallel, linked into one shared library."""
     srcs = hip_sources()
     if not force and _newer(HIP_LIB, srcs):
         return HIP_LIB
@@ -61,7 +61,8 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     if verbose:
         cflags.append("-Rpass-analysis=kernel-resource-usage")
     units = [("capi", os.path.join(CSRC, "fsmc_capi.hip"), []),
-             ("idsort", os.path.join(CSRC, "fsmc_identify_sort.hip"), [])]
+             ("idsort", os.path.join(CSRC, "fsmc_identify_sort.hip"), []),
+             ("idseeds", os.path.join(CSRC, "fsmc_identify_seeds.hip"), [])]
     units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"]) for k in KT_MEMBERS]
     units += [(f"w2_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_W2={k}"]) for k in W2_MEMBERS]
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))

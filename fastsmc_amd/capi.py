@@ -33,7 +33,7 @@ SYMBOLS = [
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
     "fsmc_decode_ibd",
     "fsmc_decode_posteriors", "fsmc_decode_per_pair", "fsmc_decode_sums", "fsmc_decode_sums_batches",
-    "fsmc_identify", "fsmc_identify_fetch",
+    "fsmc_identify", "fsmc_identify_ex", "fsmc_identify_fetch",
 ]
 
 PAIR_DTYPE = np.dtype([("hap_a", "<u4"), ("hap_b", "<u4")])
@@ -53,6 +53,11 @@ class FsmcError(RuntimeError):
 class _JobWindow(C.Structure):
     _fields_ = [("window_size", C.c_uint32), ("w_i", C.c_uint32), ("w_j", C.c_uint32), ("last_job", C.c_int32),
                 ("j_above_diag", C.c_int32)]
+
+
+class _IdentifyOpts(C.Structure):
+    _fields_ = [("word_size", C.c_uint32), ("haploid", C.c_uint32), ("max_seeds", C.c_int32),
+                ("read_ahead", C.c_uint32)]
 
 
 class _ModelDesc(C.Structure):
@@ -113,6 +118,8 @@ def load():
         L.fsmc_decode_sums_batches.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
         L.fsmc_identify.argtypes = [vp, vp, u32, u32, vp, C.POINTER(_JobWindow), vp, u32, i32, C.c_float, C.c_float, vp,
                                     sz, C.POINTER(sz)]
+        L.fsmc_identify_ex.argtypes = [vp, vp, u32, u32, vp, C.POINTER(_JobWindow), vp, u32, i32, C.c_float, C.c_float,
+                                       C.POINTER(_IdentifyOpts), vp, sz, C.POINTER(sz)]
         L.fsmc_identify_fetch.argtypes = [vp, vp, sz, C.POINTER(sz)]
         _lib = L
     return _lib
@@ -266,10 +273,11 @@ class Context:
         return self.decode_ibd_fetch()
 
     def identify(self, words, global_ids, gen_pos, *, window_size=0, w_i=1, w_j=1, last_job=True, j_above_diag=False,
-                 gap=1, skip=0.0, min_m=1.0) -> np.ndarray:
-        """The identification step (fsmc_identify): candidates (hap_a, hap_b, from, to, flush_word) in emission order.
-        ``words``: uint64 [n_haps][n_words]; ``global_ids``: haplotype numbers in the whole file; ``gen_pos``: Morgans
-        per site.  The defaults of the job window are those of a single job (every pair belongs to it)."""
+                 gap=1, skip=0.0, min_m=1.0, word_size=64, haploid=True, max_seeds=0, read_ahead=10) -> np.ndarray:
+        """The identification step (fsmc_identify_ex): candidates (hap_a, hap_b, from, to, flush_word) in emission
+        order.  ``words``: uint64 [n_haps][n_words]; ``global_ids``: haplotype numbers in the whole file; ``gen_pos``:
+        Morgans per site.  The defaults of the job window are those of a single job (every pair belongs to it); the
+        defaults of the last four are the reference's (DecodingParams.hpp)."""
         w = np.ascontiguousarray(words, np.uint64)
         if w.ndim != 2:
             raise ValueError("words must be [n_haps][n_words]")
@@ -278,12 +286,13 @@ class Context:
         if ids.shape != (w.shape[0],):
             raise ValueError("global_ids must have one entry per haplotype")
         jw = _JobWindow(window_size, w_i, w_j, int(bool(last_job)), int(bool(j_above_diag)))
+        opts = _IdentifyOpts(word_size, int(bool(haploid)), max_seeds, read_ahead)
         cap = max(1024, 4 * w.shape[0])
         while True:
             out = np.zeros(cap, CANDIDATE_DTYPE)
             n = C.c_size_t(0)
-            rc = self._L.fsmc_identify(self._h, _p(w), w.shape[0], w.shape[1], _p(ids), C.byref(jw), _p(gen), gen.size,
-                                       gap, skip, min_m, _p(out), cap, C.byref(n))
+            rc = self._L.fsmc_identify_ex(self._h, _p(w), w.shape[0], w.shape[1], _p(ids), C.byref(jw), _p(gen),
+                                          gen.size, gap, skip, min_m, C.byref(opts), _p(out), cap, C.byref(n))
             if rc == -6:  # FSMC_EOVERFLOW: n holds the count, the finished list waits on the device
                 cap = int(n.value)
                 out = np.zeros(cap, CANDIDATE_DTYPE)

@@ -23,6 +23,9 @@ namespace fsmc
 {
 hipError_t idSortCandidates(hipStream_t stream, const fsmc_candidate* in, fsmc_candidate* sorted, unsigned n,
                             unsigned nHaps, unsigned nWords); // fsmc_identify_sort.hip
+hipError_t idSeedDepths(hipStream_t stream, const unsigned long long* words, unsigned nHaps, unsigned nWords,
+                        unsigned maxSeeds, unsigned readAhead, unsigned char* depthOut,
+                        unsigned hapStride); // fsmc_identify_seeds.hip
 }
 
 using namespace fsmc;
@@ -1288,8 +1291,32 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
                   const fsmc_job_window* job, const float* gen_pos, uint32_t n_sites, int32_t gap, float skip,
                   float min_m, fsmc_candidate* out, size_t cap, size_t* n_out)
 {
+  const fsmc_identify_opts defaults = {64u, 1u, 0, 10u}; // DecodingParams.hpp: hashingWordSize, haploid, max_seeds,
+                                                         // constReadAhead
+  return fsmc_identify_ex(ctx, words, n_haps, n_words, global_ids, job, gen_pos, n_sites, gap, skip, min_m, &defaults,
+                          out, cap, n_out);
+}
+
+int fsmc_identify_ex(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_t n_words,
+                     const uint32_t* global_ids, const fsmc_job_window* job, const float* gen_pos, uint32_t n_sites,
+                     int32_t gap, float skip, float min_m, const fsmc_identify_opts* opts, fsmc_candidate* out,
+                     size_t cap, size_t* n_out)
+{
   if (!ctx) {
     return FSMC_EINVAL;
+  }
+  if (!opts) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: opts is null");
+  }
+  if (opts->word_size < 1 || opts->word_size > 64) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: word_size must be 1..64 (a word is one 64-bit integer)");
+  }
+  const bool splitSeeds = opts->max_seeds > 0; // (SeedHash.hpp:75 compares as unsigned long: a negative one never splits)
+  if (splitSeeds && (opts->read_ahead < 1 || opts->read_ahead > 32)) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: read_ahead must be 1..32 when max_seeds is set");
+  }
+  if (!opts->haploid && (n_haps & 1u)) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: haploid = 0 pairs rows 2k, 2k+1 -- n_haps must be even");
   }
   if (!n_out) {
     return fail(ctx, FSMC_EINVAL, "fsmc_identify: n_out is null");
@@ -1301,8 +1328,8 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
   if (!words || !global_ids || !job || !gen_pos || (cap && !out)) {
     return fail(ctx, FSMC_EINVAL, "fsmc_identify: null argument");
   }
-  if ((uint64_t)n_words * 64u > n_sites) {
-    return fail(ctx, FSMC_EINVAL, "fsmc_identify: n_words * 64 exceeds n_sites");
+  if ((uint64_t)n_words * opts->word_size > n_sites) {
+    return fail(ctx, FSMC_EINVAL, "fsmc_identify: n_words * word_size exceeds n_sites");
   }
   if (gap < 0 || cap > 0xFFFFFFFFull) {
     return fail(ctx, FSMC_EINVAL, "fsmc_identify: gap < 0 or cap beyond 2^32");
@@ -1312,7 +1339,7 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
   const unsigned chunks = (n_words + kIdChunk - 1) / kIdChunk;
   // device buffers of this call (one call per job: no caching)
   struct Bufs {
-    void* p[7] = {};
+    void* p[8] = {};
     ~Bufs()
     {
       for (void* q : p) {
@@ -1322,14 +1349,15 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
       }
     }
   } b;
-  const size_t bytes[7] = {(size_t)n_haps * n_words * sizeof(uint64_t),
+  const size_t bytes[8] = {(size_t)n_haps * n_words * sizeof(uint64_t),
                            (size_t)n_haps * sizeof(uint32_t),
                            (size_t)n_sites * sizeof(float),
                            (size_t)chunks * tiles * kIdTile * sizeof(unsigned),
                            (size_t)chunks * sizeof(unsigned),
                            std::max<size_t>(cap, 1) * sizeof(fsmc_candidate),
-                           sizeof(unsigned)};
-  for (int i = 0; i < 7; ++i) {
+                           sizeof(unsigned),
+                           splitSeeds ? (size_t)chunks * kIdChunk * tiles * kIdTile : 16};
+  for (int i = 0; i < 8; ++i) {
     const hipError_t e = hipMalloc(&b.p[i], bytes[i]);
     if (e != hipSuccess) {
       b.p[i] = nullptr;
@@ -1358,13 +1386,36 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
   p.out = (fsmc_candidate*)b.p[5];
   p.cap = (unsigned)cap;
   p.count = (unsigned*)b.p[6];
+  p.wordSize = opts->word_size;
+  p.depth = splitSeeds ? (const unsigned char*)b.p[7] : nullptr;
+  // id_match_kernel is the default case (haplotype pairs, whole seeds); the other settings take the general kernel
+  const bool general = splitSeeds || !opts->haploid;
+  const bool haploid = opts->haploid != 0;
+  auto launchMatch = [&]() {
+    if (!general) {
+      hipLaunchKernelGGL(id_match_kernel, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
+    } else if (haploid) {
+      hipLaunchKernelGGL(id_match_general_kernel<true>, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
+    } else {
+      hipLaunchKernelGGL(id_match_general_kernel<false>, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
+    }
+    return hipGetLastError();
+  };
   FSMC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (splitSeeds) {
+    FSMC_HIP(ctx, hipMemsetAsync(b.p[7], 0, bytes[7], ctx->stream));
+    const hipError_t e = idSeedDepths(ctx->stream, p.words, n_haps, n_words, (unsigned)opts->max_seeds, opts->read_ahead,
+                                      (unsigned char*)b.p[7], p.hapStride);
+    if (e != hipSuccess) {
+      return fail(ctx, e == hipErrorOutOfMemory ? FSMC_ENOMEM : FSMC_EHIP,
+                  std::string("fsmc_identify: splitting the seeds failed: ") + hipGetErrorString(e));
+    }
+  }
   hipLaunchKernelGGL(id_dup_kernel, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
   FSMC_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(id_complexity_kernel, dim3(chunks), dim3(kIdThreads), 0, ctx->stream, p);
   FSMC_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(id_match_kernel, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
-  FSMC_HIP(ctx, hipGetLastError());
+  FSMC_HIP(ctx, launchMatch());
   FSMC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->timed = true;
   unsigned count = 0;
@@ -1384,8 +1435,7 @@ int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_
       p.cap = count;
       e = hipMemsetAsync(b.p[6], 0, bytes[6], ctx->stream);
       if (e == hipSuccess) {
-        hipLaunchKernelGGL(id_match_kernel, dim3(tiles, tiles), dim3(kIdThreads), 0, ctx->stream, p);
-        e = hipGetLastError();
+        e = launchMatch();
       }
       if (e == hipSuccess && ensure(ctx, ctx->idStash, (size_t)count * sizeof(fsmc_candidate)) == FSMC_OK) {
         e = idSortCandidates(ctx->stream, (const fsmc_candidate*)full, (fsmc_candidate*)ctx->idStash.p, count, n_haps,

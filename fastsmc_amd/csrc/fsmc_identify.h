@@ -47,6 +47,9 @@ struct IdParams {
   fsmc_candidate* out;
   unsigned cap;
   unsigned* count;
+  unsigned wordSize;          // sites per word (DecodingParams::hashingWordSize)
+  const unsigned char* depth; // max_seeds != 0: [word][hapStride] depth at which a haplotype's seed of that word stops
+                              // being split (fsmc_identify_seeds.hip); else null
 };
 
 // SeedHash.hpp:93-128 with ind_i = the later and ind_j = the earlier haplotype of the pair
@@ -183,6 +186,7 @@ constexpr int kIdStage = 512;
 struct IdSink {
   const float* gen;
   unsigned nSites;
+  unsigned wordSize;
   float minM;
   fsmc_candidate* out;
   unsigned cap;
@@ -195,8 +199,8 @@ __device__ __forceinline__ void idReport(const IdSink& p, const unsigned hapA, c
 {
   fsmc_candidate* const stage = p.stage;
   unsigned* const nStaged = p.nStaged;
-  const size_t s0 = (size_t)64 * (size_t)start;
-  size_t s1 = (size_t)64 * (size_t)end + 63;
+  const size_t s0 = (size_t)p.wordSize * (size_t)start;
+  size_t s1 = (size_t)p.wordSize * (size_t)end + (p.wordSize - 1u);
   if (s1 > (size_t)p.nSites - 1) {
     s1 = (size_t)p.nSites - 1;
   }
@@ -205,8 +209,8 @@ __device__ __forceinline__ void idReport(const IdSink& p, const unsigned hapA, c
     fsmc_candidate c;
     c.hap_a = hapA;
     c.hap_b = hapB;
-    c.from = (unsigned)start * 64u;
-    c.to = (unsigned)end * 64u + 63u;
+    c.from = (unsigned)start * p.wordSize;
+    c.to = (unsigned)end * p.wordSize + (p.wordSize - 1u);
     c.flush_word = (unsigned)flushWord;
     const unsigned slot = atomicAdd(nStaged, 1u);
     if (slot < (unsigned)kIdStage) {
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(kIdThreads, 4) void id_match_kernel(const IdParams 
   if (!anyInJob) {
     return; // no pair of this tile belongs to the job
   }
-  const IdSink sink = {p.gen, p.nSites, p.minM, p.out, p.cap, p.count, stage, &nStaged};
+  const IdSink sink = {p.gen, p.nSites, p.wordSize, p.minM, p.out, p.cap, p.count, stage, &nStaged};
   auto report = [&](const int r, const int flushWord) {
     idReport(sink, bi * kIdTile + ty + 8u * r, j, start[r], end[r], flushWord);
   };
@@ -361,6 +365,194 @@ __global__ __launch_bounds__(kIdThreads, 4) void id_match_kernel(const IdParams 
   for (int r = 0; r < 4; ++r) {
     if (open[r]) {
       report(r, (int)p.nWords);
+    }
+  }
+  __syncthreads();
+  if (nStaged != 0u) {
+    flushStage();
+  }
+}
+
+// pass 3, the general form: matches keyed by individual pairs (haploid = false, ExtendHash.hpp:47-70) and/or seeds
+// split by the words ahead (max_seeds, SeedHash.hpp:41-85).  The same tiles; what differs from id_match_kernel:
+//   * a thread's four haplotype pairs are (row[r], col[r]) and feed NS state machines: haploid -- the four pairs of
+//     id_match_kernel, one machine each; not haploid -- the 2 x 2 haplotype pairs of ONE pair of individuals (a tile is
+//     16 x 16 individuals), one machine: any of the four extends it, the candidate names the first haplotype of each
+//     (locationToPair), and on the diagonal the two haplotypes of one individual are a pair;
+//   * with max_seeds a pair is extended at word c only if it also shares the D words after it, D = depth[c][row], and
+//     then to word c + D: the equality masks of the NEXT chunk are computed one chunk ahead (D <= read_ahead - 1 <= 31);
+//   * the words are walked one by one (an interval's end can lie ahead of the current word).
+template <bool HAPLOID>
+__global__ __launch_bounds__(kIdThreads, 4) void id_match_general_kernel(const IdParams p)
+{
+  const unsigned bi = blockIdx.y, bj = blockIdx.x;
+  if (bi > bj) {
+    return;
+  }
+  __shared__ unsigned long long As[kIdChunk][kIdTile + 1];
+  __shared__ unsigned long long Bs[kIdChunk][kIdTile + 1];
+  __shared__ unsigned char depthA[kIdChunk][kIdTile];
+  __shared__ fsmc_candidate stage[kIdStage];
+  __shared__ unsigned nStaged, stageBase;
+  __shared__ int anyInJob;
+  constexpr int NS = HAPLOID ? 4 : 1;
+  unsigned row[4], col[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (HAPLOID) {
+      row[r] = (threadIdx.x >> 5) + 8u * r;
+      col[r] = threadIdx.x & 31u;
+    } else {
+      row[r] = 2u * (threadIdx.x >> 4) + (unsigned)(r >> 1);
+      col[r] = 2u * (threadIdx.x & 15u) + (unsigned)(r & 1);
+    }
+  }
+  unsigned ok[4];
+  int start[NS], end[NS];
+  bool open[NS];
+  if (threadIdx.x == 0) {
+    anyInJob = 0;
+    nStaged = 0u;
+  }
+  __syncthreads();
+  bool mine = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned i = bi * kIdTile + row[r], j = bj * kIdTile + col[r];
+    const bool in = i < j && j < p.nHaps && idPairInJob(p.job, p.globalId[j], p.globalId[i]);
+    ok[r] = in ? ~0u : 0u;
+    mine = mine || in;
+  }
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    open[m] = false;
+    start[m] = 0;
+    end[m] = 0;
+  }
+  if (mine) {
+    anyInJob = 1;
+  }
+  __syncthreads();
+  if (!anyInJob) {
+    return;
+  }
+  const IdSink sink = {p.gen, p.nSites, p.wordSize, p.minM, p.out, p.cap, p.count, stage, &nStaged};
+  auto report = [&](const int m, const int flushWord) {
+    const unsigned a = bi * kIdTile + (HAPLOID ? row[m] : row[0]); // (row[0], col[0]): haplotype 1 of each individual
+    const unsigned b = bj * kIdTile + (HAPLOID ? col[m] : col[0]);
+    idReport(sink, a, b, start[m], end[m], flushWord);
+  };
+  auto flushStage = [&]() {
+    const unsigned n = nStaged < (unsigned)kIdStage ? nStaged : (unsigned)kIdStage;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      stageBase = atomicAdd(p.count, n);
+      nStaged = 0u;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n; i += kIdThreads) {
+      if (stageBase + i < p.cap) {
+        p.out[stageBase + i] = stage[i];
+      }
+    }
+  };
+  auto masks = [&](unsigned (&m)[4]) {
+    m[0] = m[1] = m[2] = m[3] = 0u;
+#pragma unroll 8
+    for (int w = 0; w < kIdChunk; ++w) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        m[r] |= (As[w][row[r]] == Bs[w][col[r]] ? 1u : 0u) << w;
+      }
+    }
+  };
+  unsigned mCur[4], mNext[4];
+  idLoadTile(As, p, bi * kIdTile, 0u);
+  idLoadTile(Bs, p, bj * kIdTile, 0u);
+  __syncthreads();
+  masks(mCur);
+  for (unsigned w0 = 0, chunk = 0; w0 < p.nWords; w0 += kIdChunk, ++chunk) {
+    __syncthreads();
+    if (nStaged >= (unsigned)kIdStage / 2) {
+      flushStage();
+      __syncthreads();
+    }
+    // the next chunk's words (zeros beyond the matrix: never looked at, c + D < words read) and this chunk's depths
+    idLoadTile(As, p, bi * kIdTile, w0 + kIdChunk);
+    idLoadTile(Bs, p, bj * kIdTile, w0 + kIdChunk);
+#pragma unroll
+    for (int q = 0; q < (kIdTile * kIdChunk) / kIdThreads; ++q) {
+      const unsigned idx = threadIdx.x + q * kIdThreads;
+      const unsigned w = idx / kIdTile, h = idx % kIdTile;
+      unsigned char d = 0;
+      if (p.depth && w0 + w < p.nWords) {
+        d = p.depth[(size_t)(w0 + w) * p.hapStride + bi * kIdTile + h];
+      }
+      depthA[w][h] = d;
+    }
+    __syncthreads();
+    masks(mNext);
+    const unsigned used = p.usedBits[chunk];
+    const unsigned nw = p.nWords - w0 < (unsigned)kIdChunk ? p.nWords - w0 : (unsigned)kIdChunk;
+    unsigned long long eq[4];
+    unsigned long long any = 0ull;
+    bool anyOpen = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      eq[r] = (unsigned long long)(mCur[r] & ok[r]) | ((unsigned long long)(mNext[r] & ok[r]) << 32);
+      any |= eq[r] & (unsigned long long)used;
+      mCur[r] = mNext[r];
+    }
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      anyOpen = anyOpen || open[m];
+    }
+    if (any == 0ull && !anyOpen) {
+      continue; // (no barrier is skipped: the loop's barriers are above)
+    }
+    for (unsigned w = 0; w < nw; ++w) {
+      const int cur = (int)(w0 + w);
+      if ((used >> w) & 1u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = HAPLOID ? r : 0;
+          if ((eq[r] >> w) & 1ull) {
+            // SeedHash::extendAllPairs / subHash: the pair must share the D words after this one as well
+            const unsigned D = depthA[w][row[r]];
+            const unsigned long long need = (2ull << D) - 1ull;
+            if (((eq[r] >> w) & need) == need) {
+              const int to = cur + (int)D;
+              if (!open[m]) { // ExtendHash::extendPair (ExtendHash.hpp:73-80): a new interval starts at the CURRENT word
+                open[m] = true;
+                start[m] = cur;
+                end[m] = to;
+              } else if (to > end[m]) {
+                end[m] = to;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < NS; ++m) {
+          if (open[m] && end[m] < cur - p.gap) { // clearPairsPriorTo(cur - gap), ExtendHash.hpp:85-105
+            report(m, cur);
+            open[m] = false;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < NS; ++m) {
+          if (open[m]) {
+            end[m] = cur; // extendAllPairsTo (ExtendHash.hpp:100-104) ASSIGNS the current word
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    if (open[m]) {
+      report(m, (int)p.nWords);
     }
   }
   __syncthreads();

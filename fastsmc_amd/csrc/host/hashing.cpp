@@ -17,20 +17,18 @@ double cmBetween(const int w1, const int w2, const std::vector<float>& gen, cons
 
 HashingPrefilter::HashingPrefilter(const Data& data, const DecodingParams& params) : mData(data), mParams(params)
 {
-  if (params.hashingWordSize != 64) {
-    throw std::runtime_error("hashingWordSize must be 64 (one packed genotype word)");
+  if (params.hashingWordSize < 1 || params.hashingWordSize > 64) {
+    // Individuals::getWordHash is bitset::to_ulong() (Individuals.hpp:46-50): a word is one 64-bit integer
+    throw std::runtime_error("hashingWordSize must be 1..64 (a word is hashed as one 64-bit integer)");
   }
-  if (params.max_seeds != 0) {
-    throw std::runtime_error("max_seeds != 0 (sub-hashing of large seeds) is not supported");
+  if (params.constReadAhead < 1 || (params.max_seeds > 0 && params.constReadAhead > 32)) {
+    throw std::runtime_error("constReadAhead must be at least 1, and at most 32 when max_seeds is set");
   }
-  if (!params.haploid) {
-    // the reference's default is haploid = true (DecodingParams.hpp:72); with false it keys matches by INDIVIDUAL pairs
-    // (ExtendHash::pairToLocation / locationToPair) and decodes haplotypes 2i, 2j only -- a different candidate set
-    throw std::runtime_error("haploid = false (matches keyed by individual) is not supported");
-  }
+  mWordSize = static_cast<unsigned>(params.hashingWordSize);
   mNumHaps = data.numHapRows();
   const size_t S = static_cast<size_t>(data.sites);
-  if (params.min_maf <= 0.f) {
+  const size_t W = mWordSize;
+  if (params.min_maf <= 0.f && W == 64) {
     // only complete words are hashed (FastSMC.cpp:186-195: a word counts once its 64th site has been read)
     mNumWords = S / 64;
     mWords.resize(mNumHaps * mNumWords);
@@ -44,22 +42,26 @@ HashingPrefilter::HashingPrefilter(const Data& data, const DecodingParams& param
     // word numbers then count kept sites only, exactly as in the reference
     std::vector<size_t> kept;
     for (size_t s = 0; s < S; ++s) {
-      // FastSMC.cpp:154-166: frequency of allele '1' over every haplotype of the file
-      const int total = data.totalSamplesCount[s];
-      const int ones = (data.foldToMinorAlleles && data.siteWasFlippedDuringFolding[s])
-                           ? total - data.derivedAlleleCounts[s]
-                           : data.derivedAlleleCounts[s];
-      const auto maf = static_cast<float>(ones / static_cast<double>(total));
-      if (!(maf < params.min_maf || maf > 1 - params.min_maf)) {
-        kept.push_back(s);
+      if (params.min_maf > 0.f) {
+        // FastSMC.cpp:154-166: frequency of allele '1' over every haplotype of the file
+        const int total = data.totalSamplesCount[s];
+        const int ones = (data.foldToMinorAlleles && data.siteWasFlippedDuringFolding[s])
+                             ? total - data.derivedAlleleCounts[s]
+                             : data.derivedAlleleCounts[s];
+        const auto maf = static_cast<float>(ones / static_cast<double>(total));
+        if (maf < params.min_maf || maf > 1 - params.min_maf) {
+          continue;
+        }
       }
+      kept.push_back(s);
     }
-    mNumWords = kept.size() / 64;
+    // bit b of word w = the allele of the b-th kept site of the word (Individuals::setMarker(w, snp_ctr))
+    mNumWords = kept.size() / W;
     mWords.assign(mNumHaps * mNumWords, 0ull);
     for (size_t h = 0; h < mNumHaps; ++h) {
-      for (size_t i = 0; i < mNumWords * 64; ++i) {
+      for (size_t i = 0; i < mNumWords * W; ++i) {
         if (data.genotype(h, kept[i])) {
-          mWords[h * mNumWords + i / 64] |= 1ull << (i % 64);
+          mWords[h * mNumWords + i / W] |= 1ull << (i % W);
         }
       }
     }
@@ -100,13 +102,16 @@ void HashingPrefilter::flush(const int priorTo, const int currentWord, const boo
   std::sort(done.begin(), done.end()); // the defined emission order
   for (const uint64_t key : done) {
     const Match& m = mExtend.at(key);
-    const double mlen = cmBetween(m.start(), m.end(), mData.geneticPositions, 64);
+    const int W = static_cast<int>(mWordSize);
+    const double mlen = cmBetween(m.start(), m.end(), mData.geneticPositions, W);
     if (mlen >= mParams.min_m) {
       HashingCandidate c;
-      c.hapA = static_cast<unsigned>(key / mNumHaps);
-      c.hapB = static_cast<unsigned>(key % mNumHaps);
-      c.from = static_cast<unsigned>(m.start() * 64);
-      c.to = static_cast<unsigned>(m.end() * 64 + 63);
+      // ExtendHash::locationToPair (ExtendHash.hpp:47-53): not haploid -- the first haplotype of each individual
+      const unsigned scale = mParams.haploid ? 1u : 2u;
+      c.hapA = scale * static_cast<unsigned>(key / mNumHaps);
+      c.hapB = scale * static_cast<unsigned>(key % mNumHaps);
+      c.from = static_cast<unsigned>(m.start() * W);
+      c.to = static_cast<unsigned>(m.end() * W + W - 1);
       out.push_back(c);
     }
     mExtend.erase(key);
@@ -131,10 +136,16 @@ std::vector<HashingCandidate> HashingPrefilter::runOnDevice(fsmc_ctx* ctx) const
   jw.j_above_diag = mData.is_j_above_diag ? 1 : 0;
   std::vector<fsmc_candidate> buf(std::max<size_t>(1024, 4 * mNumHaps));
   size_t n = 0;
+  fsmc_identify_opts opts{};
+  opts.word_size = mWordSize;
+  opts.haploid = mParams.haploid ? 1u : 0u;
+  opts.max_seeds = mParams.max_seeds;
+  opts.read_ahead = static_cast<uint32_t>(mParams.constReadAhead);
   auto call = [&]() {
-    return fsmc_identify(ctx, mWords.data(), static_cast<uint32_t>(mNumHaps), static_cast<uint32_t>(mNumWords), ids.data(),
-                         &jw, mData.geneticPositions.data(), static_cast<uint32_t>(mData.geneticPositions.size()),
-                         mParams.gap, mParams.skip, mParams.min_m, buf.data(), buf.size(), &n);
+    return fsmc_identify_ex(ctx, mWords.data(), static_cast<uint32_t>(mNumHaps), static_cast<uint32_t>(mNumWords),
+                            ids.data(), &jw, mData.geneticPositions.data(),
+                            static_cast<uint32_t>(mData.geneticPositions.size()), mParams.gap, mParams.skip,
+                            mParams.min_m, &opts, buf.data(), buf.size(), &n);
   };
   int rc = call();
   if (rc == FSMC_EOVERFLOW) {
@@ -155,12 +166,56 @@ std::vector<HashingCandidate> HashingPrefilter::runOnDevice(fsmc_ctx* ctx) const
   return out;
 }
 
+void HashingPrefilter::extendSeeds(const std::vector<unsigned>& members, const unsigned long w, const int cur,
+                                   const unsigned long wordsRead)
+{
+  // SeedHash::extendAllPairs (SeedHash.hpp:62-135) for the seeds of word w among `members`
+  std::vector<std::pair<uint64_t, unsigned>> order(members.size());
+  for (size_t i = 0; i < members.size(); ++i) {
+    order[i] = {mWords[members[i] * mNumWords + w], members[i]};
+  }
+  std::sort(order.begin(), order.end());
+  std::vector<unsigned> seed;
+  for (size_t a = 0; a < order.size();) {
+    size_t b = a;
+    while (b < order.size() && order[b].first == order[a].first) {
+      ++b;
+    }
+    if (mParams.max_seeds != 0 && b - a > static_cast<unsigned long>(mParams.max_seeds) && w + 1 < wordsRead) {
+      // a large seed is split by the next word, only the pairs of the sub-seeds go on (SeedHash.hpp:41-55, 75-85)
+      seed.clear();
+      for (size_t i = a; i < b; ++i) {
+        seed.push_back(order[i].second);
+      }
+      const std::vector<unsigned> sub = seed; // (the recursion reuses `seed`)
+      extendSeeds(sub, w + 1, cur, wordsRead);
+    } else {
+      for (size_t i = a; i < b; ++i) {
+        for (size_t ii = i + 1; ii < b; ++ii) {
+          const unsigned lo = order[i].second, hi = order[ii].second; // sorted: lo < hi
+          if (pairInJob(hi, lo)) {
+            // ExtendHash::extendPair (ExtendHash.hpp:73-80) with pairToLocation (60-70)
+            const uint64_t x = mParams.haploid ? lo : lo / 2, y = mParams.haploid ? hi : hi / 2;
+            auto it = mExtend.emplace(x * mNumHaps + y, Match(mWordSize, cur)).first;
+            it->second.extend(static_cast<int>(w)); // (a new interval is [cur, 0] extended to w >= cur)
+          }
+        }
+      }
+    }
+    a = b;
+  }
+}
+
 template <typename Sink> void HashingPrefilter::run(Sink&& sink)
 {
   std::vector<std::pair<uint64_t, unsigned>> order(mNumHaps);
+  std::vector<unsigned> everyone(mNumHaps);
+  for (size_t h = 0; h < mNumHaps; ++h) {
+    everyone[h] = static_cast<unsigned>(h);
+  }
   std::vector<HashingCandidate> out;
   for (unsigned long w = 0; w < mNumWords; ++w) {
-    // SeedHash: haplotypes with the same word form a seed (SeedHash.hpp:41-45)
+    // SeedHash: haplotypes with the same word form a seed (SeedHash.hpp:29-33)
     for (size_t h = 0; h < mNumHaps; ++h) {
       order[h] = {mWords[h * mNumWords + w], static_cast<unsigned>(h)};
     }
@@ -175,24 +230,10 @@ template <typename Sink> void HashingPrefilter::run(Sink&& sink)
       a = b;
     }
     const int cur = static_cast<int>(w);
+    // FastSMC.cpp:186-195: one more word is read per word processed, constReadAhead of them before the first
+    const unsigned long wordsRead = std::min<unsigned long>(mNumWords, w + static_cast<unsigned long>(mParams.constReadAhead));
     if (static_cast<float>(seeds) / static_cast<float>(mNumHaps) > mParams.skip) {
-      for (size_t a = 0; a < mNumHaps;) {
-        size_t b = a;
-        while (b < mNumHaps && order[b].first == order[a].first) {
-          ++b;
-        }
-        for (size_t i = a; i < b; ++i) {
-          for (size_t ii = i + 1; ii < b; ++ii) {
-            const unsigned lo = order[i].second, hi = order[ii].second; // sorted: lo < hi
-            if (pairInJob(hi, lo)) {
-              // ExtendHash::extendPair (ExtendHash.hpp:73-80)
-              auto it = mExtend.emplace(static_cast<uint64_t>(lo) * mNumHaps + hi, Match(64, cur)).first;
-              it->second.extend(cur);
-            }
-          }
-        }
-        a = b;
-      }
+      extendSeeds(everyone, w, cur, wordsRead);
       out.clear();
       flush(cur - mParams.gap, cur, false, out);
       for (const auto& c : out) {

@@ -65,11 +65,13 @@ public:
 private:
   bool pairInJob(unsigned hapI, unsigned hapJ) const; // SeedHash.hpp:93-128 (hapJ < hapI, local rows)
   void flush(int priorTo, int currentWord, bool all, std::vector<HashingCandidate>& out);
+  void extendSeeds(const std::vector<unsigned>& members, unsigned long w, int cur, unsigned long wordsRead);
 
   const Data& mData;
   const DecodingParams& mParams;
   std::vector<uint64_t> mWords; // [hap][word] (possibly MAF filtered)
   unsigned long mNumWords = 0;
+  unsigned mWordSize = 64;
   size_t mNumHaps = 0;
   std::unordered_map<uint64_t, Match> mExtend; // key = lower * n + higher
 };

@@ -194,6 +194,29 @@ typedef struct {
 int fsmc_identify(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_t n_words, const uint32_t* global_ids,
                   const fsmc_job_window* job, const float* gen_pos, uint32_t n_sites, int32_t gap, float skip,
                   float min_m, fsmc_candidate* out, size_t cap, size_t* n_out);
+/* The other knobs of the reference's identification step (DecodingParams.hpp: hashingWordSize, haploid, max_seeds,
+ * constReadAhead); fsmc_identify is fsmc_identify_ex with {64, 1, 0, 10}.
+ *   word_size   sites per word, 1..64: word w of a haplotype holds sites w*word_size .. +word_size-1 in its LOW bits
+ *               (Individuals.hpp:39-50); from/to and the centimorgan test count in these words.
+ *   haploid     0: matches are keyed by INDIVIDUAL pairs (ExtendHash.hpp:47-70: haplotype ids rounded down to the
+ *               individual, rows 2k and 2k+1 of the matrix): any of the (up to four) haplotype pairs of the job extends
+ *               the pair's one interval, the two haplotypes of one individual form a pair, and the candidate names
+ *               rows (2 * ind_a, 2 * ind_b), ind_a <= ind_b (locationToPair).  n_haps must be even.
+ *   max_seeds   != 0: a seed with more than max_seeds haplotypes is split by the NEXT word, and again, while the words
+ *               read ahead last (SeedHash.hpp:41-85): only the pairs that also share those words are extended, to the
+ *               last word looked at.
+ *   read_ahead  words buffered ahead of the current one, 1..32 (FastSMC.cpp:186-195: while word c is processed
+ *               min(n_words, c + read_ahead) words have been read); bounds the splitting above. */
+typedef struct {
+  uint32_t word_size;
+  uint32_t haploid;
+  int32_t max_seeds;
+  uint32_t read_ahead;
+} fsmc_identify_opts;
+int fsmc_identify_ex(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint32_t n_words,
+                     const uint32_t* global_ids, const fsmc_job_window* job, const float* gen_pos, uint32_t n_sites,
+                     int32_t gap, float skip, float min_m, const fsmc_identify_opts* opts, fsmc_candidate* out,
+                     size_t cap, size_t* n_out);
 /* After an fsmc_identify that returned FSMC_EOVERFLOW (*n_out = the count): the complete candidate list of that call, in
  * emission order -- it was finished and kept on the device, so the caller allocates *n_out records and fetches them
  * instead of running the identification a second time.  The kept list is released by the fetch. */

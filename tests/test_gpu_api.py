@@ -177,6 +177,31 @@ def test_fastsmc_run_with_hashing_matches_oracle_text(files, small_problem, tmp_
     assert got == want
 
 
+@pytest.mark.parametrize("opts", [dict(haploid=False, min_m=0.4),
+                                  dict(max_seeds=2, hashingWordSize=32, constReadAhead=6, min_m=0.8)])
+def test_fastsmc_run_with_the_other_hashing_knobs(files, small_problem, tmp_path, opts):
+    """The same run with matches keyed by individual pairs (haploid = false: the candidates name haplotype 1 of each
+    individual and include an individual with itself, HMM.cpp:483-486 decodes what it is given) and with large seeds
+    split by the words read ahead (max_seeds)."""
+    from test_hashing import restate_candidates, restate_kwargs
+
+    sp = small_problem
+    out = str(tmp_path / "hashknobs")
+    p = _params(files, out, hashing=True, **opts)
+    api.FastSMC(p).run()
+    got = gzip.open(out + ".1.1.FastSMC.ibd.gz", "rt").read()
+    individuals = list(range(32))
+    cands = restate_candidates(sp["haps"].alleles, sp["gen"], individuals, **restate_kwargs(opts))
+    assert len(cands) >= 20
+    if not opts.get("haploid", True):
+        assert any(a == b for a, b, _, _ in cands)
+    recs, pairs = _oracle_hashing_records(sp, sp["folded"], sp["model"], cands)
+    ids = [f"1_{d + 1}" for d in individuals]
+    want = O.format_ibd_text(recs, pairs, ids, ids, 1, sp["haps"].bp, sp["gen"])
+    assert want.count("\n") > 10
+    assert got == want
+
+
 def test_binary_output_round_trip(files, small_problem, tmp_path):
     """BIN_OUT writes the .bibd.gz layout of HMM.cpp:383-401 / 1146-1176; read it back with BinaryDataReader and
     compare with the text run (ibd_score is fp32 in the binary file, double in the text file)."""

@@ -14,7 +14,7 @@ import pytest
 
 from fastsmc_amd import api, capi, synth
 from oracle import oracle as O
-from test_hashing import _params, restate_candidates
+from test_hashing import OTHER_KNOBS, _params, restate_candidates, restate_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -42,6 +42,39 @@ def test_device_candidates_equal_the_restatement_and_the_host(hash_files, opts):
         assert len(want) > 20
 
 
+@pytest.mark.parametrize("opts", OTHER_KNOBS)
+def test_word_size_individual_pairs_and_split_seeds_on_the_device(hash_files, opts):
+    """hashingWordSize != 64, haploid = false (matches keyed by individual pairs) and max_seeds != 0 (large seeds split
+    by the words read ahead: fsmc_identify_seeds.hip + the general match kernel) -- equal to both restatements."""
+    root, haps = hash_files
+    p = _params(root, **opts)
+    data = api.Data(p)
+    got = [tuple(c) for c in api.hashingCandidatesDevice(data, p)]
+    want = restate_candidates(haps.alleles, (haps.cm / 100.0).astype(np.float32), list(range(40)),
+                              **restate_kwargs(opts))
+    assert got == want
+    assert got == [tuple(c) for c in api.hashingCandidates(data, p)]
+    assert len(want) > 10
+
+
+@pytest.mark.parametrize("jobs", [4])
+@pytest.mark.parametrize("opts", [dict(haploid=False), dict(max_seeds=2, constReadAhead=4),
+                                  dict(max_seeds=2, haploid=False, hashingWordSize=32)])
+def test_other_knobs_with_job_windows_on_the_device(hash_files, jobs, opts):
+    root, haps = hash_files
+    gen = (haps.cm / 100.0).astype(np.float32)
+    total = 0
+    for j in range(1, jobs + 1):
+        p = _params(root, min_m=0.5, jobs=jobs, jobInd=j, **opts)
+        data = api.Data(p)
+        individuals = O.job_individuals(40, jobs, j)
+        got = [tuple(c) for c in api.hashingCandidatesDevice(data, p)]
+        assert got == restate_candidates(haps.alleles, gen, individuals, jobs=jobs, job_ind=j, min_m=0.5,
+                                         **restate_kwargs(opts))
+        total += len(got)
+    assert total > 20
+
+
 @pytest.mark.parametrize("jobs", [4, 9])
 def test_job_windows_on_the_device(hash_files, jobs):
     root, haps = hash_files
@@ -61,15 +94,15 @@ def test_job_windows_on_the_device(hash_files, jobs):
     assert set(seen) == whole and len(whole) > 20
 
 
-def _pack_words(alleles):
+def _pack_words(alleles, word_size=64):
     n, S = alleles.shape
-    W = S // 64
-    bits = alleles[:, :W * 64].reshape(n, W, 64).astype(np.uint64)
-    return (bits << np.arange(64, dtype=np.uint64)[None, None, :]).sum(axis=2, dtype=np.uint64)
+    W = S // word_size
+    bits = alleles[:, :W * word_size].reshape(n, W, word_size).astype(np.uint64)
+    return (bits << np.arange(word_size, dtype=np.uint64)[None, None, :]).sum(axis=2, dtype=np.uint64)
 
 
 def _raw(ctx, alleles, gen, **kw):
-    words = _pack_words(alleles)
+    words = _pack_words(alleles, kw.get("word_size", 64))
     ids = np.arange(alleles.shape[0], dtype=np.uint32)
     rec = ctx.identify(words, ids, gen, **kw)
     return [(int(r["hap_a"]), int(r["hap_b"]), int(r["from"]), int(r["to"])) for r in rec], rec
@@ -87,6 +120,39 @@ def test_ragged_shapes_through_the_c_abi(n_hap, S):
         # the order is the documented one: by flush word, then by pair key
         key = rec["flush_word"].astype(np.int64) * (n_hap * n_hap) + rec["hap_a"].astype(np.int64) * n_hap + rec["hap_b"]
         assert np.all(np.diff(key) > 0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_hap,S", [(2, 64), (6, 200), (34, 64 * 33 + 5), (70, 64 * 40), (130, 64 * 7 + 63)])
+def test_ragged_shapes_with_the_other_knobs(n_hap, S):
+    """The general match kernel and the seed splitting on shapes that do not fill tiles or chunks; read-ahead windows
+    that reach past the last word; seeds of every size (max_seeds = 1 splits every seed that is not a singleton)."""
+    haps = synth.make_haps(n_hap, S, seed=n_hap + S, cm_per_mb=40.0, switch_per_cm=0.3, noise=2e-3, n_founders=5)
+    gen = (haps.cm / 100.0).astype(np.float32)
+    ctx = capi.Context(0)
+    for kw in (dict(min_m=0.0, gap=0, haploid=False), dict(min_m=0.1, gap=1, word_size=20),
+               dict(min_m=0.0, gap=1, max_seeds=1, read_ahead=2, word_size=16),
+               dict(min_m=0.0, gap=2, max_seeds=2, read_ahead=32, word_size=8, skip=0.02),
+               dict(min_m=0.05, gap=0, max_seeds=3, haploid=False, word_size=32, read_ahead=10)):
+        got, rec = _raw(ctx, haps.alleles, gen, **kw)
+        want = restate_candidates(haps.alleles, gen, list(range(n_hap // 2)), **kw)
+        assert got == want, kw
+        key = rec["flush_word"].astype(np.int64) * (n_hap * n_hap) + rec["hap_a"].astype(np.int64) * n_hap + rec["hap_b"]
+        assert np.all(np.diff(key) > 0)
+    ctx.close()
+
+
+def test_the_other_knobs_are_checked():
+    ctx = capi.Context(0)
+    gen = np.linspace(0, 0.01, 400).astype(np.float32)
+    w = np.zeros((4, 4), np.uint64)
+    ids = np.arange(4, dtype=np.uint32)
+    for bad in (dict(word_size=0), dict(word_size=65), dict(max_seeds=2, read_ahead=0), dict(max_seeds=2, read_ahead=33)):
+        with pytest.raises(capi.FsmcError):
+            ctx.identify(w, ids, gen, **bad)
+    with pytest.raises(capi.FsmcError):   # individuals are rows 2k, 2k+1
+        ctx.identify(np.zeros((5, 4), np.uint64), np.arange(5, dtype=np.uint32), gen, haploid=False)
+    assert ctx.identify(w, ids, gen, max_seeds=-1, min_m=0.0).size == 6   # (never splits: compared as unsigned long)
     ctx.close()
 
 
@@ -144,3 +210,30 @@ def test_overflow_protocol_and_a_machine_filling_cohort():
     assert len(want) > 4 * 2048  # the first buffer was too small
     assert got == want
     assert ms > 0
+
+
+def test_split_seeds_and_individual_pairs_on_a_machine_filling_cohort():
+    """The same cohort shape with large seeds (40 founders: seeds of ~50 haplotypes, max_seeds = 20 splits them, some
+    several times) and with matches keyed by individual pairs, against the host restatement (C++)."""
+    haps = synth.make_haps_blocked(1024, 32 * 160, seed=9, cm_per_mb=30.0, switch_per_cm=0.05, noise=5e-4, n_founders=40)
+    gen = (haps.cm / 100.0).astype(np.float32)
+    import tempfile
+    ctx = capi.Context(0)
+    with tempfile.TemporaryDirectory() as d:
+        root = d + "/big"
+        synth.write_haps_files(root, haps)
+        plain = None
+        for opts in (dict(), dict(max_seeds=20, constReadAhead=8), dict(haploid=False, max_seeds=20)):
+            p = _params(root, min_m=1.0, hashingWordSize=32, **opts)
+            data = api.Data(p)
+            want = [tuple(c) for c in api.hashingCandidates(data, p)]
+            kw = dict(word_size=32, haploid=opts.get("haploid", True), max_seeds=opts.get("max_seeds", 0),
+                      read_ahead=opts.get("constReadAhead", 10))
+            got, _ = _raw(ctx, haps.alleles, gen, min_m=1.0, **kw)
+            assert len(want) > 1000
+            assert got == want, opts
+            if not opts:
+                plain = want
+            elif opts.get("haploid", True):
+                assert want != plain   # the splitting changed the list
+    ctx.close()

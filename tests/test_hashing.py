@@ -52,9 +52,13 @@ def test_match_known_answers():
 
 # ---------------------------------------------------------------- candidate stream
 
-def restate_candidates(alleles, gen, individuals, *, jobs=1, job_ind=1, min_m=1.0, gap=1, skip=0.0, min_maf=0.0):
+def restate_candidates(alleles, gen, individuals, *, jobs=1, job_ind=1, min_m=1.0, gap=1, skip=0.0, min_maf=0.0,
+                       word_size=64, haploid=True, max_seeds=0, read_ahead=10):
     """FastSMC.cpp:118-235 with the emission order this product defines (ascending lower*n+higher per flush).
-    ``alleles`` are the raw alleles of EVERY haplotype of the file; ``individuals`` the ones the job loaded."""
+    ``alleles`` are the raw alleles of EVERY haplotype of the file; ``individuals`` the ones the job loaded.
+    ``word_size`` = hashingWordSize, ``haploid``: matches keyed by haplotype or by individual pairs
+    (ExtendHash.hpp:47-70), ``max_seeds``/``read_ahead``: large seeds are split by the words read ahead
+    (SeedHash.hpp:41-85, FastSMC.cpp:186-195)."""
     import math
 
     n_tot = alleles.shape[0]
@@ -87,35 +91,59 @@ def restate_candidates(alleles, gen, individuals, *, jobs=1, job_ind=1, min_m=1.
     if min_maf > 0:
         maf = (alleles.sum(axis=0) / float(n_tot)).astype(np.float32)
         keep = keep[~((maf < np.float32(min_maf)) | (maf > np.float32(1) - np.float32(min_maf)))]
-    words = len(keep) // 64
+    W = word_size
+    words = len(keep) // W
     gen = np.asarray(gen, np.float32)
     open_matches = {}
     out = []
+    scale = 1 if haploid else 2  # locationToPair: the first haplotype of each individual
 
     def emit(keys):
         for key in sorted(keys):
             s, e = open_matches.pop(key)
-            end_site = min(64 * e + 63, len(gen) - 1)
-            if 100.0 * float(np.float32(gen[end_site] - gen[64 * s])) >= float(np.float32(min_m)):
-                out.append((key // n, key % n, 64 * s, 64 * e + 63))
+            end_site = min(W * e + W - 1, len(gen) - 1)
+            if 100.0 * float(np.float32(gen[end_site] - gen[W * s])) >= float(np.float32(min_m)):
+                out.append((scale * (key // n), scale * (key % n), W * s, W * e + W - 1))
 
-    for w in range(words):
+    def word_of(local, w):
+        return alleles[rows[local], keep[W * w:W * w + W]].tobytes()
+
+    def extend_all_pairs(seeds, w, cur, words_read):  # SeedHash::extendAllPairs (SeedHash.hpp:62-135)
+        for members in seeds.values():
+            if max_seeds != 0 and len(members) > max_seeds and w + 1 < words_read:
+                sub = defaultdict(list)  # SeedHash::subHash: the seed's members by their NEXT word
+                for local in members:
+                    sub[word_of(local, w + 1)].append(local)
+                extend_all_pairs(sub, w + 1, cur, words_read)
+                continue
+            for x in range(len(members)):
+                for y in range(x + 1, len(members)):
+                    lo, hi = sorted((members[x], members[y]))
+                    if in_job(rows[hi], rows[lo]):
+                        a, b = (lo, hi) if haploid else (lo // 2, hi // 2)   # pairToLocation
+                        m = open_matches.setdefault(a * n + b, [cur, w])     # extendPair: [CURRENT word, w]
+                        m[1] = max(m[1], w)
+
+    # the word buffer (FastSMC.cpp:186-195): read_ahead words before the first is processed, then one more per word
+    words_read = cur = 0
+    while True:
+        while words_read < words:
+            words_read += 1
+            if words_read >= read_ahead:
+                break
+        if cur >= words_read:
+            break
+        w = cur
         seeds = defaultdict(list)
-        cols = keep[64 * w:64 * w + 64]
-        for local, g in enumerate(rows):
-            seeds[alleles[g, cols].tobytes()].append(local)
+        for local in range(n):
+            seeds[word_of(local, w)].append(local)
         if np.float32(len(seeds)) / np.float32(n) > np.float32(skip):
-            for members in seeds.values():
-                for x in range(len(members)):
-                    for y in range(x + 1, len(members)):
-                        lo, hi = members[x], members[y]
-                        if in_job(rows[hi], rows[lo]):
-                            m = open_matches.setdefault(lo * n + hi, [w, w])
-                            m[1] = max(m[1], w)
+            extend_all_pairs(seeds, w, cur, words_read)
             emit([k for k, m in open_matches.items() if m[1] < w - gap])
         else:
             for m in open_matches.values():
                 m[1] = w
+        cur += 1
     emit(list(open_matches))
     return out
 
@@ -176,18 +204,55 @@ def test_job_windows_partition_the_candidates(hash_files, jobs):
     assert set(seen) == whole and len(whole) > 20
 
 
-def test_word_size_and_max_seeds_are_checked(hash_files):
+OTHER_KNOBS = [dict(hashingWordSize=32, min_m=0.5), dict(hashingWordSize=17, min_m=0.3, gap=2),
+               dict(haploid=False, min_m=0.8), dict(haploid=False, hashingWordSize=48, gap=0, min_m=0.4),
+               dict(max_seeds=3, min_m=0.5), dict(max_seeds=2, constReadAhead=3, min_m=0.3, gap=2),
+               dict(max_seeds=1, hashingWordSize=8, min_m=0.2, skip=0.05),
+               dict(max_seeds=2, haploid=False, hashingWordSize=16, min_m=0.4, constReadAhead=5)]
+_RESTATE_NAMES = {"hashingWordSize": "word_size", "constReadAhead": "read_ahead"}
+
+
+def restate_kwargs(opts):
+    return {_RESTATE_NAMES.get(k, k): v for k, v in opts.items() if k != "foldData"}
+
+
+@pytest.mark.parametrize("opts", OTHER_KNOBS)
+def test_word_size_individual_pairs_and_split_seeds(hash_files, opts):
+    """hashingWordSize != 64, haploid = false and max_seeds != 0 against the restatement of the reference's loops."""
+    root, haps = hash_files
+    p = _params(root, **opts)
+    data = api.Data(p)
+    got = [tuple(c) for c in api.hashingCandidates(data, p)]
+    want = restate_candidates(haps.alleles, (haps.cm / 100.0).astype(np.float32), list(range(40)),
+                              **restate_kwargs(opts))
+    assert got == want
+    assert len(want) > 10
+    W = opts.get("hashingWordSize", 64)
+    assert all(f % W == 0 and t % W == W - 1 and t < 1500 for _, _, f, t in want)
+    if not opts.get("haploid", True):
+        assert all(a % 2 == 0 and b % 2 == 0 and a <= b for a, b, _, _ in want)
+        assert any(a == b for a, b, _, _ in want) or opts.get("max_seeds")   # the two haplotypes of one individual
+
+
+def test_split_seeds_change_the_candidates(hash_files):
+    """max_seeds really bites on this cohort (else the cases above would prove nothing): the list differs from the
+    one without it, and some interval ends beyond the last word its pair was seen to share without look-ahead."""
+    root, haps = hash_files
+    gen = (haps.cm / 100.0).astype(np.float32)
+    plain = restate_candidates(haps.alleles, gen, list(range(40)), min_m=0.5)
+    split = restate_candidates(haps.alleles, gen, list(range(40)), min_m=0.5, max_seeds=3)
+    assert plain != split and len(split) > 10
+
+
+def test_hashing_parameters_are_checked(hash_files):
     root, _ = hash_files
     p = _params(root)
     data = api.Data(p)
-    p.hashingWordSize = 32
-    with pytest.raises(RuntimeError, match="hashingWordSize"):
-        api.hashingCandidates(data, p)
+    for bad in (0, 65):
+        p.hashingWordSize = bad
+        with pytest.raises(RuntimeError, match="hashingWordSize"):
+            api.hashingCandidates(data, p)
     p.hashingWordSize = 64
-    p.max_seeds = 5
-    with pytest.raises(RuntimeError, match="max_seeds"):
-        api.hashingCandidates(data, p)
-    p.max_seeds = 0
-    p.haploid = False  # matches keyed by individual pairs (ExtendHash.hpp): another candidate set, not built
-    with pytest.raises(RuntimeError, match="haploid"):
+    p.constReadAhead = 0
+    with pytest.raises(RuntimeError, match="constReadAhead"):
         api.hashingCandidates(data, p)

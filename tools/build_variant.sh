@@ -20,6 +20,7 @@ for K in 48 64; do
   hipcc $FLAGS "$@" -DFSMC_INSTANCE_W2=$K -o $OBJ/w2_$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
 done
 hipcc $FLAGS -o $OBJ/idsort.o $ROOT/fastsmc_amd/csrc/fsmc_identify_sort.hip & PIDS="$PIDS $!"
+hipcc $FLAGS -o $OBJ/idseeds.o $ROOT/fastsmc_amd/csrc/fsmc_identify_seeds.hip & PIDS="$PIDS $!"
 for P in $PIDS; do wait $P; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib$NAME.so $OBJ/*.o
 rm -rf $OBJ
