@@ -379,6 +379,25 @@ struct LaunchPlan {
 // `items`: the list the waves will pull from when it is not the uploaded group list.  `paired`: two half-groups per
 // wave, `items` holding the union of each pair's windows.
 // `share`: the launch runs beside another one and may take 1/share of the workspace limit, in `ws`.
+// What a decode may spend on its workspace: the caller's limit if one is set (fsmc_ctx_set_workspace_limit); otherwise
+// up to 80 % of the card where that much is free -- the card has 288 GB, and the model, the haplotypes and the records
+// are small -- but never less than 40 % of it (the plan of the first rounds).  `cur`: the buffer about to be re-used.
+uint64_t workspaceBudget(const fsmc_ctx* ctx, const DevBuf& cur)
+{
+  if (ctx->wsLimit) {
+    return ctx->wsLimit;
+  }
+  const uint64_t floor40 = (uint64_t)(0.40 * (double)ctx->hbmBytes);
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
+    return floor40;
+  }
+  const uint64_t reachable = (uint64_t)freeB + cur.bytes;
+  const uint64_t margin = (uint64_t)(0.04 * (double)ctx->hbmBytes);
+  const uint64_t want = (uint64_t)(0.80 * (double)ctx->hbmBytes);
+  return std::max<uint64_t>(floor40, std::min<uint64_t>(want, reachable > margin ? reachable - margin : 0));
+}
+
 int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan,
                const std::vector<fsmc_group>* items = nullptr, bool paired = false, unsigned share = 1,
                DevBuf* ws = nullptr)
@@ -416,7 +435,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   const int member = familyMember(m);
   const size_t K4 = w2 ? (size_t)m->KP / 4 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
   const size_t vecBytes = K4 * kWave * sizeof(float4);
-  const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / share;
+  const uint64_t limit = workspaceBudget(ctx, ws ? *ws : ctx->ws) / share;
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
   const bool half = halfAvailable(mode, m) && ctx->betaStride != 1;
   auto chunkRows = [&](size_t c) { return half ? (c + 1) / 2 : c; };
@@ -452,19 +471,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   // lane-per-pair family; paired launches are single-chunk).
   size_t resident = 0;
   if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && ctx->residentChunks != 0) {
-    // (their budget: the caller's limit if one is set; otherwise up to 80 % of the card where that much is free -- the
-    //  card has 288 GB and the model, the haplotypes and the records are small -- but never less than the plan's own)
-    uint64_t budget = limit;
-    if (!ctx->wsLimit) {
-      size_t freeB = 0, totalB = 0;
-      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-        const DevBuf& cur = ws ? *ws : ctx->ws;
-        const uint64_t reachable = (uint64_t)freeB + cur.bytes;
-        const uint64_t margin = (uint64_t)(0.04 * (double)ctx->hbmBytes);
-        const uint64_t want = (uint64_t)(0.80 * (double)ctx->hbmBytes) / share;
-        budget = std::max<uint64_t>(limit, std::min<uint64_t>(want, reachable > margin ? reachable - margin : 0));
-      }
-    }
+    const uint64_t budget = limit;
     const size_t rowsBudget = (size_t)(budget / (vecBytes * slots));
     const size_t fixed = chunkRows(C) + maxChunks + 5;
     if (rowsBudget > fixed) {
@@ -1185,7 +1192,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fnDual, kWave, 0));
     const size_t slots = (size_t)ctx->nCU * std::min(std::max(blocksPerCU, 1), 8);
     const size_t vecBytes = (size_t)(familyMember(m) + 3) / 4 * kWave * sizeof(float4);
-    const uint64_t limit = (ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.40 * (double)ctx->hbmBytes)) / 2;
+    const uint64_t limit = workspaceBudget(ctx, ctx->ws) / 2;
     const size_t rowsAvail = (size_t)(limit / (vecBytes * slots));
     const bool halfDual = halfAvailable(kModeIbd, m) && ctx->betaStride != 1; // a stored row serves two sites
     maxLen = rowsAvail > 16 ? std::min<size_t>((rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
