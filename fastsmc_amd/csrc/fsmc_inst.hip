@@ -11,7 +11,7 @@ FSMC_KT_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
 FSMC_DEFINE_KT_DUAL(FSMC_INSTANCE_KT)
 #endif
 #if FSMC_INSTANCE_KT == 16 || FSMC_INSTANCE_KT == 32 || FSMC_INSTANCE_KT == 48 || FSMC_INSTANCE_KT == 64 ||           \
-    FSMC_INSTANCE_KT == 69 || FSMC_INSTANCE_KT == 96 || FSMC_INSTANCE_KT == 112 || FSMC_INSTANCE_KT == 128
+    FSMC_INSTANCE_KT == 69 || FSMC_INSTANCE_KT == 80 || FSMC_INSTANCE_KT == 96 || FSMC_INSTANCE_KT == 112 || FSMC_INSTANCE_KT == 128
 static_assert(halfBuilt(FSMC_INSTANCE_KT), "keep halfBuilt() and this list in step");
 FSMC_KT_HALF_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
 FSMC_DEFINE_KT_DUAL_HALF(FSMC_INSTANCE_KT)

@@ -24,7 +24,7 @@ namespace fsmc
 // beta stride 2 needs three K-vectors in a lane's registers: built for the members it fits
 constexpr bool halfBuilt(const int KT)
 {
-  return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 69 || KT == 96 || KT == 112 || KT == 128;
+  return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 69 || KT == 80 || KT == 96 || KT == 112 || KT == 128;
 }
 
 #define FSMC_KT_KERNELS(X, KT)                                                                                         \

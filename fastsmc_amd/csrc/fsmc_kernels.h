@@ -769,7 +769,11 @@ struct Tables {
 };
 
 // compile-time K that is a whole number of operand blocks = a padded family member (K <= KT real states)
+#ifdef FSMC_EXPERIMENT_NO_GHOST
+template <int KT> constexpr bool kGhost = false;
+#else
 template <int KT> constexpr bool kGhost = KT % kKPad == 0;
+#endif
 
 template <int KT> __device__ __forceinline__ cfloat_p rowSetOf(const Tables& t, const int row)
 {
@@ -996,7 +1000,7 @@ __device__ __forceinline__ void scanBlocks(float (&w)[KA], float& s, const float
 // 112 and 128 states keep their two or three K-vectors in registers only with the whole 512-entry file (one wave).
 constexpr int minWavesPerSimd(const int KT)
 {
-  return KT > 80 ? 1 : 2;
+  return KT >= 80 ? 1 : 2;
 }
 //
 // DUAL: two half-groups per wavefront (hashing mode: a batch is 32 pairs, half a wave).  Lanes 0..31 decode half A, lanes

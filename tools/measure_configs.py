@@ -421,12 +421,27 @@ def identify():
         rec = ctx.identify(words, ids, gen, min_m=1.0)
         dt = time.perf_counter() - t0
         ms = ctx.last_kernel_ms()
+        # the other knobs of the reference (general match kernel; seeds split by the words read ahead)
+        knobs = {}
+        for name, kw in (("haploid_false", dict(haploid=False)), ("max_seeds_50", dict(max_seeds=50)),
+                         ("word_size_32", dict(word_size=32))):
+            w2 = words
+            if "word_size" in kw:
+                W2 = S // 32
+                w2 = np.packbits(haps.alleles[:, :W2 * 32].reshape(n_hap, W2, 32), axis=2,
+                                 bitorder="little").view(np.uint32).reshape(n_hap, W2).astype(np.uint64)
+            ctx.identify(w2, ids, gen, min_m=1.0, **kw)
+            t0 = time.perf_counter()
+            r2 = ctx.identify(w2, ids, gen, min_m=1.0, **kw)
+            knobs[name] = {"candidates": int(r2.size), "kernels_ms": ctx.last_kernel_ms(),
+                           "call_s": time.perf_counter() - t0}
         ctx.close()
         pair_words = n_hap * (n_hap - 1) / 2 * W
         out = {"config": "identify", "haplotypes": n_hap, "sites": S, "words": W, "pairs": n_hap * (n_hap - 1) // 2,
                "candidates": int(rec.size), "kernels_ms": ms, "call_s": dt,
                "pair_words_per_s_two_passes": 2 * pair_words / (ms * 1e-3),
-               "lds_GBps": 2 * pair_words * 10 / (ms * 1e-3) / 1e9, "lds_peak_GBps": 128 * 256 * 2.4}
+               "lds_GBps": 2 * pair_words * 10 / (ms * 1e-3) / 1e9, "lds_peak_GBps": 128 * 256 * 2.4,
+               "other_knobs": knobs}
         if n_hap <= 1000:
             data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
             p = api.DecodingParams()
