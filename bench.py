@@ -161,7 +161,10 @@ def main() -> None:
     ap.add_argument("--flags", type=int, default=-1, help="FSMC_WANT_* bits (default: mean + MAP ages)")
     ap.add_argument("--diag-same-row", action="store_true",
                     help="diagnostic, NOT a result: every site uses the same transition-table row (scalar-cache hits)")
-    ap.add_argument("--ws-frac", type=float, default=0.0, help="workspace cap as a fraction of HBM (0 = default)")
+    ap.add_argument("--ws-frac", type=float, default=0.8,
+                    help="workspace limit as a fraction of HBM, set by the caller like a long job would (a step is a "
+                         "slice of one: the library's own default lets a context EARN its workspace over its first "
+                         "minutes, DESIGN.md 3.3 -- hipMalloc costs 40 ms per GB); 0 = that default")
     ap.add_argument("--resident-chunks", type=int, default=-1,
                     help="chunks of a chunked window whose beta rows stay in the workspace (no rebuild): -1 = as many "
                          "as memory allows, 0 = none")
@@ -296,6 +299,7 @@ def main() -> None:
                        "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
                        "chunk_sites": info["chunk_sites"], "chunks_per_window": info["max_chunks"],
                        "resident_chunks": ctx.last_resident_chunks(),
+                       "workspace_limit_frac_of_hbm": args.ws_frac,
                        "beta_stride": ctx.last_beta_stride(), "kernel_member": ctx.last_kernel(),
                        "lib_hash": lib_hash(),
                        **({"kernel_ms_per_rank": per_rank_ms,

@@ -65,6 +65,7 @@ struct fsmc_ctx {
   int nCU = 0;
   uint64_t hbmBytes = 0;
   uint64_t wsLimit = 0;
+  double wsEarned = 0; // bytes of workspace the launches so far have paid for (earnWorkspace)
   std::string err;
 
   unsigned long long* dHaps = nullptr;
@@ -379,23 +380,61 @@ struct LaunchPlan {
 // `items`: the list the waves will pull from when it is not the uploaded group list.  `paired`: two half-groups per
 // wave, `items` holding the union of each pair's windows.
 // `share`: the launch runs beside another one and may take 1/share of the workspace limit, in `ws`.
-// What a decode may spend on its workspace: the caller's limit if one is set (fsmc_ctx_set_workspace_limit); otherwise
-// up to 80 % of the card where that much is free -- the card has 288 GB, and the model, the haplotypes and the records
-// are small -- but never less than 40 % of it (the plan of the first rounds).  `cur`: the buffer about to be re-used.
-uint64_t workspaceBudget(const fsmc_ctx* ctx, const DevBuf& cur)
+// What a decode may spend on its workspace.
+// The most it can have (`hard`): the caller's limit if one is set (fsmc_ctx_set_workspace_limit); otherwise 80 % of the
+// card where that much is free (the card has 288 GB; the model, the haplotypes and the records are small), at least 40 %.
+// What its plan may be UPGRADED with (`soft`) -- a window kept whole instead of chunked, resident chunks, longer windows
+// in the paired kernel: the same when the caller set a limit (the caller knows the job).  Otherwise memory has to be
+// earned: hipMalloc costs ~40 ms per GB on this driver (230 GB: 4.4-9 s; tools/malloc_cost.py), a rebuilt chunk costs a
+// few per cent of a launch, so a run of a few seconds must not start by allocating the card.  Every launch adds what
+// it is expected to save -- kEarnFraction of its estimated kernel time -- at the allocation rate; the buffer is kept
+// between launches, so a long job reaches the full card within its first minutes and a short one stays small.
+// `cur`: the buffer about to be re-used (what it holds is paid for).
+constexpr double kAllocBytesPerSecond = 25e9; // measured: hipMalloc of 64 / 128 GB takes 2.4 / 5.2 s
+constexpr double kEarnFraction = 0.06;        // what resident chunks save of a chunked launch (C2: 1974 -> 1854 ms)
+constexpr uint64_t kFreeWorkspace = 8ull << 30; // never argued about (0.3 s)
+
+struct WsBudget {
+  uint64_t hard, soft;
+};
+
+WsBudget workspaceBudget(const fsmc_ctx* ctx, const DevBuf& cur)
 {
-  if (ctx->wsLimit) {
-    return ctx->wsLimit;
-  }
-  const uint64_t floor40 = (uint64_t)(0.40 * (double)ctx->hbmBytes);
   size_t freeB = 0, totalB = 0;
-  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
-    return floor40;
-  }
+  const bool known = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
   const uint64_t reachable = (uint64_t)freeB + cur.bytes;
   const uint64_t margin = (uint64_t)(0.04 * (double)ctx->hbmBytes);
-  const uint64_t want = (uint64_t)(0.80 * (double)ctx->hbmBytes);
-  return std::max<uint64_t>(floor40, std::min<uint64_t>(want, reachable > margin ? reachable - margin : 0));
+  if (ctx->wsLimit) {
+    // (a limit above what the card has free right now -- another process on it -- is cut to that, if it is at least
+    //  a quarter of the limit: below, the caller is told by the allocation failing)
+    uint64_t lim = ctx->wsLimit;
+    if (known && reachable > margin && reachable - margin < lim && reachable - margin >= lim / 4) {
+      lim = reachable - margin;
+    }
+    return {lim, lim};
+  }
+  const uint64_t floor40 = (uint64_t)(0.40 * (double)ctx->hbmBytes);
+  uint64_t hard = floor40;
+  if (known) {
+    const uint64_t want = (uint64_t)(0.80 * (double)ctx->hbmBytes);
+    hard = std::max<uint64_t>(floor40, std::min<uint64_t>(want, reachable > margin ? reachable - margin : 0));
+  }
+  const uint64_t earned = (uint64_t)std::min(ctx->wsEarned, 1e15);
+  const uint64_t soft = std::min<uint64_t>(hard, std::max<uint64_t>({(uint64_t)cur.bytes, earned, kFreeWorkspace}));
+  return {hard, soft};
+}
+
+// A launch over the uploaded work list earns workspace for this and the following launches: estimated kernel time =
+// algorithmic bytes at 80 % of the roofline.
+void earnWorkspace(fsmc_ctx* ctx, const fsmc_model* m, int mode)
+{
+  double pairSites = 0;
+  for (const fsmc_group& g : ctx->hGroups) {
+    const uint32_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
+    pairSites += (double)g.n_pairs * (double)(aEnd > g.from ? aEnd - g.from : 0);
+  }
+  const double seconds = pairSites * (8.0 * m->K + 0.25) / (0.8 * 8e12);
+  ctx->wsEarned += kEarnFraction * seconds * kAllocBytesPerSecond;
 }
 
 int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan,
@@ -435,14 +474,20 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   const int member = familyMember(m);
   const size_t K4 = w2 ? (size_t)m->KP / 4 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
   const size_t vecBytes = K4 * kWave * sizeof(float4);
-  const uint64_t limit = workspaceBudget(ctx, ws ? *ws : ctx->ws) / share;
+  const WsBudget budget = workspaceBudget(ctx, ws ? *ws : ctx->ws);
+  const uint64_t limit = budget.hard / share;
   // Rows a chunk of C sites needs in the chunk buffer: with beta stride 2 only every second site's row is stored.
   const bool half = halfAvailable(mode, m) && ctx->betaStride != 1;
   auto chunkRows = [&](size_t c) { return half ? (c + 1) / 2 : c; };
   const size_t rowsAvail = (size_t)(limit / (vecBytes * slots)); // rows one resident wave may hold
+  const size_t rowsSoft = (size_t)(budget.soft / share / (vecBytes * slots)); // ... and may have earned so far
+  const size_t defaultChunk = std::max<size_t>((size_t)std::ceil(std::sqrt((double)L)), w2 ? 2048 : 512);
   size_t C, maxChunks;
-  // (an explicit chunk length is kept, except for paired launches, which only have the single-chunk layout)
-  if (chunkRows(L) + 5 <= rowsAvail && !(ctx->chunkSites && ctx->chunkSites < L && !paired)) {
+  // A window stays whole if that fits what the launches have earned (or is no longer than a chunk would be anyway; a
+  // paired launch only has this layout and was planned within the same budget).
+  // (an explicit chunk length is kept, except for paired launches)
+  if (chunkRows(L) + 5 <= rowsAvail && (chunkRows(L) + 5 <= rowsSoft || L <= defaultChunk || paired) &&
+      !(ctx->chunkSites && ctx->chunkSites < L && !paired)) {
     C = L;
     maxChunks = 1;
   } else {
@@ -450,8 +495,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     // (memory is chunk + window / chunk rows), shrunk to what the workspace limit allows.  Short chunks cost a
     // checkpoint row and a pipeline restart each and let the resident chunks (below) fill the memory that is left to
     // the last row: C2 at 2048 / 1024 / 512 sites a chunk runs 1886 / 1881 / 1870 ms.
-    C = ctx->chunkSites ? (size_t)ctx->chunkSites
-                        : std::max<size_t>((size_t)std::ceil(std::sqrt((double)L)), w2 ? 2048 : 512);
+    C = ctx->chunkSites ? (size_t)ctx->chunkSites : defaultChunk;
     // (the wave-group kernel has no resident chunks and pays more per restart: 2048)
     C = std::min((C + 15) / 16 * 16, (L + 15) / 16 * 16);
     auto fits = [&](size_t c) { return chunkRows(c) + (L + c - 1) / c + 5 <= rowsAvail; };
@@ -471,8 +515,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   // lane-per-pair family; paired launches are single-chunk).
   size_t resident = 0;
   if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && ctx->residentChunks != 0) {
-    const uint64_t budget = limit;
-    const size_t rowsBudget = (size_t)(budget / (vecBytes * slots));
+    const size_t rowsBudget = rowsSoft;
     const size_t fixed = chunkRows(C) + maxChunks + 5;
     if (rowsBudget > fixed) {
       resident = std::min<size_t>((rowsBudget - fixed) / chunkRows(C), maxChunks);
@@ -1181,6 +1224,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   const bool track = (flags & (FSMC_WANT_MEAN | FSMC_WANT_MAP)) != 0;
+  earnWorkspace(ctx, m, kModeIbd);
   // The queues.  Two half-groups per wave for the half-full groups that pair up within the single-chunk layout
   // (decode_kernel<..., DUAL>, with beta stride 2 where that is built); the other groups one per wave, in a kernel that
   // runs beside it.
@@ -1190,9 +1234,11 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     fnDual = pickKernel(kModeIbd, track, m, true);
     int blocksPerCU = 0;
     FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fnDual, kWave, 0));
-    const size_t slots = (size_t)ctx->nCU * std::min(std::max(blocksPerCU, 1), 8);
+    // (no more waves than groups: a short list leaves each of them more of the budget)
+    const size_t slots = std::max<size_t>(
+        1, std::min<size_t>((size_t)ctx->nCU * std::min(std::max(blocksPerCU, 1), 8), ctx->hGroups.size()));
     const size_t vecBytes = (size_t)(familyMember(m) + 3) / 4 * kWave * sizeof(float4);
-    const uint64_t limit = workspaceBudget(ctx, ctx->ws) / 2;
+    const uint64_t limit = workspaceBudget(ctx, ctx->ws).soft / 2;
     const size_t rowsAvail = (size_t)(limit / (vecBytes * slots));
     const bool halfDual = halfAvailable(kModeIbd, m) && ctx->betaStride != 1; // a stored row serves two sites
     maxLen = rowsAvail > 16 ? std::min<size_t>((rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
@@ -1609,6 +1655,7 @@ int fsmc_decode_posteriors(fsmc_ctx* ctx, const fsmc_model* m, float* out, size_
   }
   KernelFn fn = pickKernel(kModeDump, false, m);
   LaunchPlan plan;
+  earnWorkspace(ctx, m, kModeDump);
   rc = planLaunch(ctx, m, kModeDump, fn, plan);
   if (rc == FSMC_OK) rc = ensure(ctx, ctx->aux, offsets.size() * sizeof(size_t));
   if (rc == FSMC_OK) rc = ensure(ctx, ctx->out, total * sizeof(float));
@@ -1642,6 +1689,7 @@ int fsmc_decode_per_pair(fsmc_ctx* ctx, const fsmc_model* m, const float* exp_co
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   KernelFn fn = pickKernel(kModePerPair, false, m);
   LaunchPlan plan;
+  earnWorkspace(ctx, m, kModePerPair);
   rc = planLaunch(ctx, m, kModePerPair, fn, plan);
   if (rc != FSMC_OK) {
     return rc;
@@ -1717,6 +1765,7 @@ int fsmc_decode_sums_batches(fsmc_ctx* ctx, const fsmc_model* m, const uint32_t*
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   KernelFn fn = pickKernel(kModeSums, false, m);
   LaunchPlan plan;
+  earnWorkspace(ctx, m, kModeSums);
   rc = planLaunch(ctx, m, kModeSums, fn, plan);
   if (rc != FSMC_OK) {
     return rc;

@@ -1,6 +1,9 @@
 #include "hashing.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -255,8 +258,17 @@ template <typename Sink> void HashingPrefilter::run(Sink&& sink)
 
 void runHashing(const Data& data, const DecodingParams& params, HMM& hmm)
 {
+  using Clock = std::chrono::steady_clock;
+  const bool timing = std::getenv("FSMC_HOST_TIMING") != nullptr;
+  Clock::time_point t0 = Clock::now();
   HashingPrefilter pf(data, params);
+  const double tWords = std::chrono::duration<double>(Clock::now() - t0).count();
+  t0 = Clock::now();
   const std::vector<HashingCandidate> all = pf.runOnDevice(hmm.engine());
+  if (timing) {
+    std::fprintf(stderr, "[fsmc host] hashing words %.3f s, identification (engine + fsmc_identify) %.3f s, %zu candidates\n",
+                 tWords, std::chrono::duration<double>(Clock::now() - t0).count(), all.size());
+  }
   // sharded: every rank runs the identification step and decodes a contiguous range of the resulting batches, so
   // each batch has the composition -- hence the window -- of a single-device run.  The ranges have equal pair-site
   // WEIGHT, not equal batch counts (the windows differ in length): the reference's own range rule total*r/R

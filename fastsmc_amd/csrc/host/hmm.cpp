@@ -5,6 +5,9 @@
 #include "hmm.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <cmath>
 #include <iomanip>
 #include <limits>
@@ -599,13 +602,18 @@ void HMM::flush()
   }
   ensureEngine();
   const size_t nPairs = mBatchBegin; // pairs covered by closed batches
+  using Clock = std::chrono::steady_clock;
+  auto since = [](const Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); };
+  Clock::time_point t0 = Clock::now();
   check(mCtx, fsmc_worklist_upload(mCtx, mPairs.data(), nPairs, mGroups.data(), mGroups.size()),
         "fsmc_worklist_upload");
+  mTimeUpload += since(t0);
 
   if (mParams.FastSMC) {
     uint32_t flags = 0;
     if (mParams.doPerPairPosteriorMean) flags |= FSMC_WANT_MEAN;
     if (mParams.doPerPairMAP) flags |= FSMC_WANT_MAP;
+    t0 = Clock::now();
     check(mCtx, fsmc_decode_ibd_launch(mCtx, mModel, flags), "fsmc_decode_ibd_launch");
     std::vector<fsmc_ibd_record> recs(std::max<size_t>(1024, 4 * nPairs));
     size_t n = 0;
@@ -615,12 +623,15 @@ void HMM::flush()
       rc = fsmc_decode_ibd_fetch(mCtx, recs.data(), recs.size(), &n);
     }
     check(mCtx, rc, "fsmc_decode_ibd_fetch");
+    mTimeDecode += since(t0);
+    t0 = Clock::now();
     for (size_t i = 0; i < n; ++i) {
       if (mKeepRecords) {
         mKeptOrdinals.push_back(mPairsFlushed + recs[i].pair);
       }
       writeIbd(mPairs[recs[i].pair], recs[i]);
     }
+    mTimeWrite += since(t0);
   }
   if (mParams.doPosteriorSums || mParams.doMajorMinorPosteriorSums) {
     const bool mm = mParams.doMajorMinorPosteriorSums;
@@ -866,6 +877,10 @@ void HMM::finishFromHashing()
   closeBatch(true);
   flush();
   closeIBDFile();
+  if (std::getenv("FSMC_HOST_TIMING")) {
+    std::fprintf(stderr, "[fsmc host] work-list upload %.3f s, decode (launch + fetch) %.3f s, records out %.3f s\n",
+                 mTimeUpload, mTimeDecode, mTimeWrite);
+  }
 }
 
 void HMM::closeIBDFile()

@@ -188,6 +188,8 @@ private:
   std::vector<unsigned> mFromBatch, mToBatch; // per slot of the open batch (hashing mode), HMM.cpp:491-493
   unsigned long mHashingCount = 0;            // "cpt"
   size_t mFlushThreshold = 1u << 20;
+  // FSMC_HOST_TIMING=1: seconds spent in the phases of flush(), printed by finishFromHashing / finishDecoding
+  double mTimeUpload = 0, mTimeDecode = 0, mTimeWrite = 0;
   int mShardRank = 0, mShardWorld = 1;
 
   // outputs

@@ -118,10 +118,10 @@ def test_windows_too_long_to_pair_run_in_the_second_kernel(small_problem):
     ctx = capi.Context(0)
     model = ctx.create_model(pm)
     ctx.upload_haps(small_problem["bits"], S)
-    # the pairing budget is what a FULL machine of resident waves could hold: ~200 rows of 18 float4 x 64 lanes per wave on
-    # 256 CUs x 8 waves (half of that beside a second kernel) -- with beta stride 2 enough for windows of up to 387 sites,
-    # not for the 640-site ones
-    ctx.set_workspace_limit(200 * 18 * 64 * 16 * 256 * 8)
+    # the pairing budget is what the resident waves could hold -- no more waves than groups: ~200 rows of 18 float4 x 64
+    # lanes for each of the seven (half of that beside a second kernel) -- with beta stride 2 enough for windows of up to
+    # 387 sites, not for the 640-site ones
+    ctx.set_workspace_limit(200 * 18 * 64 * 16 * len(shapes))
     plain, n0 = _run(ctx, model, pairs, wins, flags, pairing=0)
     paired, n1 = _run(ctx, model, pairs, wins, flags, pairing=1)
     ctx.close()

@@ -393,10 +393,21 @@ def short_windows():
     ctx.upload_haps(bits, pm.S)
     ctx.upload_worklist(pr, groups)
     ps = float((lens.astype(np.int64) * 32).sum())
-    for pairing in (1, 0):
+    # workspace: the limit a long job sets or has earned (the regime's steady state: every window whole, the long ones
+    # pair up too), then pairing off, then -- in a fresh context -- the library's own policy for a job this short
+    # (memory is earned by the work done: the few 5504-site windows are decoded in chunks)
+    ctx.set_workspace_limit(int(0.8 * ctx.info()["hbm_bytes"]))
+    for pairing, policy in ((1, "limit 0.8 of HBM"), (0, "limit 0.8 of HBM"), (1, "earned (default)")):
+        if policy.startswith("earned"):
+            ctx.close()
+            ctx = capi.Context(0)
+            model = ctx.create_model(pm)
+            ctx.upload_haps(bits, pm.S)
+            ctx.upload_worklist(pr, groups)
         ctx.set_pairing(pairing)
         dt, rec = timed(lambda: (ctx.decode_ibd_launch(model), ctx.decode_ibd_fetch())[1])
-        print(json.dumps({"config": "short_windows_ibd", "pairing": pairing, "wave_items": ctx.last_items(),
+        print(json.dumps({"config": "short_windows_ibd", "pairing": pairing, "workspace": policy,
+                          "wave_items": ctx.last_items(),
                           "beta_stride": ctx.last_beta_stride(), "groups": n_groups, "pairs": int(pr.size),
                           "pair_sites": ps, "seconds": dt, "kernel_ms": ctx.last_kernel_ms(),
                           "pair_sites_per_s": ps / dt, "pairs_per_s": pr.size / dt,
