@@ -420,7 +420,11 @@ WsBudget workspaceBudget(const fsmc_ctx* ctx, const DevBuf& cur)
     hard = std::max<uint64_t>(floor40, std::min<uint64_t>(want, reachable > margin ? reachable - margin : 0));
   }
   const uint64_t earned = (uint64_t)std::min(ctx->wsEarned, 1e15);
-  const uint64_t soft = std::min<uint64_t>(hard, std::max<uint64_t>({(uint64_t)cur.bytes, earned, kFreeWorkspace}));
+  uint64_t freeBytes = kFreeWorkspace;
+  if (const char* v = std::getenv("FSMC_DIAG_WS_FREE")) { // tests: make the policy visible on a small problem
+    freeBytes = std::strtoull(v, nullptr, 10);
+  }
+  const uint64_t soft = std::min<uint64_t>(hard, std::max<uint64_t>({(uint64_t)cur.bytes, earned, freeBytes}));
   return {hard, soft};
 }
 
@@ -434,7 +438,11 @@ void earnWorkspace(fsmc_ctx* ctx, const fsmc_model* m, int mode)
     pairSites += (double)g.n_pairs * (double)(aEnd > g.from ? aEnd - g.from : 0);
   }
   const double seconds = pairSites * (8.0 * m->K + 0.25) / (0.8 * 8e12);
-  ctx->wsEarned += kEarnFraction * seconds * kAllocBytesPerSecond;
+  double scale = 1.0;
+  if (const char* v = std::getenv("FSMC_DIAG_WS_EARN_SCALE")) { // tests: a small problem that earns like a long job
+    scale = std::atof(v);
+  }
+  ctx->wsEarned += scale * kEarnFraction * seconds * kAllocBytesPerSecond;
 }
 
 int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan,

@@ -657,7 +657,10 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 // Work item = one group of <= 64 pairs; workgroup = kW2NW waves; two workgroups per CU (the landing zones fill LDS).
 // SEQ: sequence mode (two steps per site, a fourth emission row per site: fsmc_kernels.h) -- the same schedule as there.
 template <int KH, int MODE, bool TRACK, bool SEQ = false>
-__global__ __launch_bounds__(kW2NW * kWave, 2) void decode_kernel_w2(const KParams p)
+#ifndef FSMC_W2_WG_PER_CU
+#define FSMC_W2_WG_PER_CU 2
+#endif
+__global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kernel_w2(const KParams p)
 {
   static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums || MODE == kModePerPair,
                 "the consumers of the wave-group kernel");

@@ -57,3 +57,37 @@ def test_resident_chunks_setting_is_validated(small_problem):
     with pytest.raises(capi.FsmcError):
         ctx.set_resident_chunks(-2)
     ctx.close()
+
+
+def test_workspace_is_earned_without_a_limit(small_problem, monkeypatch):
+    """Without a caller's limit a plan is upgraded (here: resident chunks) only with memory the context's launches have
+    paid for (hipMalloc costs 40 ms per GB).  Made visible on a small problem by two diagnostic
+    switches: the free allowance down to one byte, and an earning rate that turns this launch into a long job's."""
+    n = WINS[-1][0] + WINS[-1][1]
+    pairs = O.enumerate_all_pairs(32)[500:500 + n]
+    groups = np.zeros(len(WINS), capi.GROUP_DTYPE)
+    for g, w in zip(groups, WINS):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
+
+    def run(launches):
+        ctx, model = _ctx(small_problem, 2, limit=0, chunk=48)
+        out = []
+        for _ in range(launches):
+            rec = ctx.decode_ibd(model, _pairs_array(pairs), groups, flags)
+            out.append((ctx.last_resident_chunks(), rec.tobytes()))
+        chunks = ctx.info()["max_chunks"]
+        ctx.close()
+        return out, chunks
+
+    monkeypatch.setenv("FSMC_DIAG_WS_FREE", "1")
+    poor, chunks = run(3)
+    assert chunks > 10 and [r for r, _ in poor] == [0, 0, 0]     # nothing earned to speak of: every chunk rebuilt
+    monkeypatch.setenv("FSMC_DIAG_WS_EARN_SCALE", "1e9")
+    rich, _ = run(2)
+    assert rich[0][0] == chunks and rich[1][0] == chunks          # the launch itself pays for its upgrade
+    monkeypatch.delenv("FSMC_DIAG_WS_FREE")
+    monkeypatch.delenv("FSMC_DIAG_WS_EARN_SCALE")
+    free, _ = run(1)
+    assert free[0][0] == chunks                                   # a problem this small fits the free allowance
+    assert len({b for _, b in poor + rich + free}) == 1           # the records do not depend on the plan
