@@ -769,11 +769,7 @@ struct Tables {
 };
 
 // compile-time K that is a whole number of operand blocks = a padded family member (K <= KT real states)
-#ifdef FSMC_EXPERIMENT_NO_GHOST
-template <int KT> constexpr bool kGhost = false;
-#else
 template <int KT> constexpr bool kGhost = KT % kKPad == 0;
-#endif
 
 template <int KT> __device__ __forceinline__ cfloat_p rowSetOf(const Tables& t, const int row)
 {

@@ -656,10 +656,13 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 
 // Work item = one group of <= 64 pairs; workgroup = kW2NW waves; two workgroups per CU (the landing zones fill LDS).
 // SEQ: sequence mode (two steps per site, a fourth emission row per site: fsmc_kernels.h) -- the same schedule as there.
-template <int KH, int MODE, bool TRACK, bool SEQ = false>
+// (-DFSMC_W2_WG_PER_CU=1, an experiment: one workgroup per CU gets 512 registers a lane -- 256 + 102 accumulation
+//  registers, no scratch instead of 165 spilled -- and runs 1.43 times faster by itself, but the CU then idles in the two
+//  phases of four a wave has no work in: C4 3.59 -> 4.96 s.)
 #ifndef FSMC_W2_WG_PER_CU
 #define FSMC_W2_WG_PER_CU 2
 #endif
+template <int KH, int MODE, bool TRACK, bool SEQ = false>
 __global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kernel_w2(const KParams p)
 {
   static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums || MODE == kModePerPair,
