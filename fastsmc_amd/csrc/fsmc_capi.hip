@@ -392,7 +392,7 @@ struct LaunchPlan {
 // `cur`: the buffer about to be re-used (what it holds is paid for).
 constexpr double kAllocBytesPerSecond = 25e9; // measured: hipMalloc of 64 / 128 GB takes 2.4 / 5.2 s
 constexpr double kEarnFraction = 0.06;        // what resident chunks save of a chunked launch (C2: 1974 -> 1854 ms)
-constexpr uint64_t kFreeWorkspace = 8ull << 30; // never argued about (0.3 s)
+constexpr uint64_t kFreeWorkspace = 24ull << 30; // never argued about (at most a second; only what a plan uses is allocated)
 
 struct WsBudget {
   uint64_t hard, soft;
