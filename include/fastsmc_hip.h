@@ -121,14 +121,20 @@ void fsmc_ctx_destroy(fsmc_ctx* ctx);
 const char* fsmc_last_error(const fsmc_ctx* ctx);
 /* Device properties as seen by the library: CU count, and the number of resident decode waves it launches. */
 int fsmc_ctx_info(const fsmc_ctx* ctx, int32_t* n_cu, int32_t* n_slots, uint64_t* hbm_bytes);
-/* Cap on the workspace the library may allocate for alpha/beta streaming (bytes; 0 = default 40 % of HBM). */
+/* Workspace for the alpha/beta streaming (bytes).  A limit set here is the caller's statement about the job: a plan may
+ * use all of it at once -- windows kept whole instead of chunked, resident chunks, long windows in the paired kernel.
+ * 0 (default): the library's own policy.  The rows a decode cannot do without may take up to 80 % of the card (at least
+ * 40 %); everything beyond them is EARNED: hipMalloc costs about 40 ms per GB on this driver, so a context starts with a
+ * free allowance of 24 GB and every launch adds what an upgraded plan is expected to save of it (6 % of its estimated
+ * kernel time, at the allocation rate) -- a job of minutes has the whole card after its first minutes, a run of seconds
+ * does not spend them allocating.  The buffer is kept for the life of the context. */
 int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes);
-/* Tuning: sites between beta checkpoints when a decode window does not fit the workspace (0 = automatic,
- * ceil(sqrt(window)) rounded up to 16).  Results do not depend on it. */
+/* Tuning: sites between beta checkpoints when a decode window does not fit the workspace (0 = automatic:
+ * max(512, ceil(sqrt(window))), 2048 for the wave-group kernel, rounded up to 16).  Results do not depend on it. */
 int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites);
 /* Tuning: beta stride of the IBD decode.  1 = every beta row of a chunk goes through HBM (8K bytes per pair-site);
  * 2 = every second row does and the alpha sweep recomputes the others from their successor (4K bytes per
- * pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (array mode; K <= 69 and 81 ... 128), else 1.
+ * pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (array mode, K <= 128), else 1.
  * Results do not depend on it.  fsmc_ctx_last_beta_stride reports what the last IBD launch used. */
 int fsmc_ctx_set_beta_stride(fsmc_ctx* ctx, uint32_t stride);
 int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
@@ -137,8 +143,8 @@ int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
 int fsmc_ctx_last_plan(const fsmc_ctx* ctx, int32_t* chunk_sites, int32_t* max_chunks, int32_t* n_slots);
 /* Chunked windows (longer than a wave's workspace holds) rebuild every chunk's beta rows from a checkpoint -- one of the
  * decode's 3.5 sweeps -- except for the window's first chunks, whose rows the backward pass can leave in the workspace
- * ("resident chunks").  chunks = -1 (default): as many as memory allows -- the workspace limit if one is set, otherwise up
- * to 80 % of the card where that much is free; 0: none; n: at most n.  Results do not depend on it. */
+ * ("resident chunks").  chunks = -1 (default): as many as the workspace allows (the limit if one is set, otherwise what
+ * the context has earned: see fsmc_ctx_set_workspace_limit); 0: none; n: at most n.  Results do not depend on it. */
 int fsmc_ctx_set_resident_chunks(fsmc_ctx* ctx, int32_t chunks);
 int fsmc_ctx_last_resident_chunks(const fsmc_ctx* ctx, int32_t* chunks);
 /* Two half-groups per wavefront.  A group of at most 32 pairs (a hashing-mode batch of the reference's default size)
