@@ -327,8 +327,37 @@ unsigned blockThreads(int mode, const fsmc_model* m)
   return waveGroups(mode, m) ? (unsigned)(kW2NW * kWave) : (unsigned)kWave;
 }
 
+// more than 256 states: the any-K kernel (fsmc_kernels_any.h)
+bool anyStates(const fsmc_model* m)
+{
+  return m->K > kMaxStates;
+}
+
+template <bool SEQ> KernelFn pickAnyKernel(int mode, bool track)
+{
+  switch (mode) {
+  case kModeIbd:
+    return track ? decode_kernel_any<kModeIbd, true, SEQ> : decode_kernel_any<kModeIbd, false, SEQ>;
+  case kModeDump:
+    return decode_kernel_any<kModeDump, false, SEQ>;
+  case kModePerPair:
+    return decode_kernel_any<kModePerPair, false, SEQ>;
+  case kModeSums:
+    return decode_kernel_any<kModeSums, false, SEQ>;
+  default:
+    return nullptr;
+  }
+}
+
 KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false)
 {
+  if (anyStates(m)) {
+    if (mode == kModeIbd) {
+      m->ctx->lastStride = 1;
+    }
+    m->ctx->lastMember = 0;
+    return m->sequence ? pickAnyKernel<true>(mode, track) : pickAnyKernel<false>(mode, track);
+  }
   if (waveGroups(mode, m)) {
     if (mode == kModeIbd) {
       m->ctx->lastStride = 1;
@@ -489,12 +518,14 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   auto chunkRows = [&](size_t c) { return half ? (c + 1) / 2 : c; };
   const size_t rowsAvail = (size_t)(limit / (vecBytes * slots)); // rows one resident wave may hold
   const size_t rowsSoft = (size_t)(budget.soft / share / (vecBytes * slots)); // ... and may have earned so far
+  // rows beside the chunk buffer and the checkpoints: parking / segment sums; the any-K kernel keeps every vector there
+  const size_t sideRows = anyStates(m) ? (size_t)kAnyExtraRows + 2 : 4;
   const size_t defaultChunk = std::max<size_t>((size_t)std::ceil(std::sqrt((double)L)), w2 ? 2048 : 512);
   size_t C, maxChunks;
   // A window stays whole if that fits what the launches have earned (or is no longer than a chunk would be anyway; a
   // paired launch only has this layout and was planned within the same budget).
   // (an explicit chunk length is kept, except for paired launches)
-  if (chunkRows(L) + 5 <= rowsAvail && (chunkRows(L) + 5 <= rowsSoft || L <= defaultChunk || paired) &&
+  if (chunkRows(L) + sideRows + 1 <= rowsAvail && (chunkRows(L) + sideRows + 1 <= rowsSoft || L <= defaultChunk || paired) &&
       !(ctx->chunkSites && ctx->chunkSites < L && !paired)) {
     C = L;
     maxChunks = 1;
@@ -506,7 +537,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     C = ctx->chunkSites ? (size_t)ctx->chunkSites : defaultChunk;
     // (the wave-group kernel has no resident chunks and pays more per restart: 2048)
     C = std::min((C + 15) / 16 * 16, (L + 15) / 16 * 16);
-    auto fits = [&](size_t c) { return chunkRows(c) + (L + c - 1) / c + 5 <= rowsAvail; };
+    auto fits = [&](size_t c) { return chunkRows(c) + (L + c - 1) / c + sideRows + 1 <= rowsAvail; };
     if (!ctx->chunkSites) {
       while (C > 16 && !fits(C)) {
         C = std::max<size_t>(16, (C / 2 + 15) / 16 * 16);
@@ -522,9 +553,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   // one chunk buffer, the checkpoints and the parking rows goes to such chunks (array-mode IBD decode of the
   // lane-per-pair family; paired launches are single-chunk).
   size_t resident = 0;
-  if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && ctx->residentChunks != 0) {
+  if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && !anyStates(m) && ctx->residentChunks != 0) {
     const size_t rowsBudget = rowsSoft;
-    const size_t fixed = chunkRows(C) + maxChunks + 5;
+    const size_t fixed = chunkRows(C) + maxChunks + sideRows + 1;
     if (rowsBudget > fixed) {
       resident = std::min<size_t>((rowsBudget - fixed) / chunkRows(C), maxChunks);
       if (ctx->residentChunks > 0) {
@@ -536,7 +567,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   plan.chunkRows = (int)chunkRows(C);
   plan.maxChunks = (int)maxChunks;
   plan.residentChunks = (int)resident;
-  plan.wsSlot = (chunkRows(C) * (1 + resident) + maxChunks + 2 + 2) * K4 * kWave;
+  plan.wsSlot = (chunkRows(C) * (1 + resident) + maxChunks + 2 + (sideRows - 2)) * K4 * kWave;
   plan.slots = (int)slots;
   ctx->lastChunk = plan.chunk;
   ctx->lastMaxChunks = plan.maxChunks;
@@ -572,8 +603,8 @@ int checkReady(fsmc_ctx* ctx, const fsmc_model* m)
       return fail(ctx, FSMC_EINVAL, "group window exceeds the number of sites");
     }
   }
-  if (m->K > kMaxStates) {
-    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxStates) + " states");
+  if (m->K > kMaxStatesAny) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxStatesAny) + " states");
   }
   return FSMC_OK;
 }
@@ -878,8 +909,8 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   if (d->K < 2 || d->S < 1 || d->n_rows < 1) {
     return fail(ctx, FSMC_EINVAL, "need K >= 2, S >= 1, n_rows >= 1");
   }
-  if (d->K > kMaxStates) {
-    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxStates) + " states");
+  if (d->K > kMaxStatesAny) {
+    return fail(ctx, FSMC_EUNSUPPORTED, "more than " + std::to_string(kMaxStatesAny) + " states");
   }
   if (!d->pi || !d->col_ratios || !d->exp_times || !d->D || !d->B || !d->U || !d->RR || !d->step_row || !d->e1 ||
       !d->e0m1 || !d->e2m0) {
@@ -911,9 +942,9 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   m->ctx = ctx;
   m->K = d->K;
   m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
-  if (d->K > 128) {
+  if (d->K > 128 && d->K <= kMaxStates) {
     // wide models: four waves per group hold KP/4 states each (fsmc_kernels_w2.h); the padding states are ghosts
-    m->KP = d->K <= 128 ? 128 : d->K <= 192 ? 192 : 256;
+    m->KP = d->K <= 192 ? 192 : 256;
   }
   m->S = d->S;
   m->nRows = d->n_rows;

@@ -11,11 +11,14 @@
 //   KT = 96, 112, 128     80 < K <= 128: the same kernel with one wave per SIMD (512 registers a lane)
 // Wave-group kernel (decode_kernel_w2<KH, MODE, TRACK, SEQ>), lane = pair and four waves per group: 128 < K <= 256,
 //   KH = 48, 64 states per wave.
+// Any-K kernel (decode_kernel_any<MODE, TRACK, SEQ>, fsmc_kernels_any.h): K > 256, a pair's K-vectors in the workspace
+//   instead of registers -- correct, not fast; small enough to be instantiated where it is picked (fsmc_capi.hip).
 // (The runtime-K instantiation KT = 0 and the four-lanes-per-pair kernel of earlier builds are gone: every model of at
-//  most 256 states, in every mode, runs one of the kernels above.)
+//  most 256 states, in every mode, runs one of the two families above.)
 #pragma once
 
 #include "fsmc_kernels.h"
+#include "fsmc_kernels_any.h"
 #include "fsmc_kernels_w2.h"
 
 namespace fsmc

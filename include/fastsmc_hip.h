@@ -156,7 +156,8 @@ int fsmc_ctx_set_pairing(fsmc_ctx* ctx, uint32_t mode);
 int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items);
 /* Which kernel the last launch ran: 16 ... 128 = the lane-per-pair kernel compiled for that many states (69, or the
  * padded members 16, 32, 48, 64, 80, 96, 112, 128); 1048 / 1064 = the four-waves-per-group kernel with 48 / 64 states
- * per wave (128 < K <= 256). */
+ * per wave (128 < K <= 256); 0 = the any-K kernel (256 < K <= 4096: a pair's K-vectors live in the workspace instead of
+ * registers -- the same results, far from the roofline). */
 int fsmc_ctx_last_kernel(const fsmc_ctx* ctx, int32_t* member);
 
 /* ---- resident inputs ---- */

@@ -23,12 +23,14 @@ def _problem(K, n_hap=64, S=200, seed=11):
 
 
 def _member(K, consumer="ibd"):
-    """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; beyond, the four-waves-per-group
-    kernel (1000 + states per wave)."""
+    """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; up to 256 the four-waves-per-group
+    kernel (1000 + states per wave); beyond, 0 = the any-K kernel (a pair's K-vectors in the workspace)."""
     if K == 69:
         return 69
     if K <= 128:
         return (K + 15) // 16 * 16
+    if K > 256:
+        return 0
     return 1000 + (48 if K <= 192 else 64)
 
 
@@ -36,7 +38,7 @@ def _stride(K):
     return 2 if K <= 128 else 1  # every member of the lane-per-pair family is built with beta stride 2
 
 
-@pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 50, 64, 65, 70, 80, 81, 100, 128, 130, 192, 200, 256])
+@pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 50, 64, 65, 70, 80, 81, 100, 128, 130, 192, 200, 256, 257, 300, 402])
 def test_generic_kernel_matches_oracle(K):
     pm, bits, folded = _problem(K)
     pairs = O.enumerate_all_pairs(32)[:96]
@@ -72,7 +74,7 @@ def test_generic_kernel_matches_oracle(K):
     wsum = np.zeros((pm.S, pm.K), np.float32)
     O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
     np.testing.assert_array_equal(s, wsum)
-    if K in (5, 100, 200, 256):  # the 00 / 01 / 11 split in one member of each kernel
+    if K in (5, 100, 200, 256, 300):  # the 00 / 01 / 11 split in one member of each kernel
         s2, mm = ctx.decode_sums(model, major_minor=True)
         want = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
         O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, want[0], want[1], want[2], want[3])
@@ -136,17 +138,71 @@ def test_wide_model_scan_thresholds_that_reach_the_upper_waves(K, time):
 
 
 def test_too_many_states_is_rejected():
+    """Up to 256 states a kernel holds a pair's vectors in registers; beyond, the any-K kernel keeps them in the workspace
+    (tested above: 257, 300, 402 states); the library's limit is 4096."""
     pm, bits, _ = _problem(16)
     ctx = capi.Context(0)
     import copy
     big = copy.copy(pm)
-    big.K = 300  # every array widened to 300 states: the shapes are consistent, the C side refuses the size
-    pad = lambda a: np.pad(np.asarray(a, np.float32), [(0, 0)] * (np.ndim(a) - 1) + [(0, 300 - pm.K)])  # noqa: E731
+    big.K = 4100  # every array widened: the shapes are consistent, the C side refuses the size
+    pad = lambda a: np.pad(np.asarray(a, np.float32), [(0, 0)] * (np.ndim(a) - 1) + [(0, big.K - pm.K)])  # noqa: E731
     for f in ("pi", "col_ratios", "exp_times", "D", "B", "U", "RR", "e1", "e0m1", "e2m0"):
         setattr(big, f, pad(getattr(pm, f)))
     with pytest.raises(capi.FsmcError):
         ctx.create_model(big)
     ctx.close()
+
+
+@pytest.mark.parametrize("K", [300])
+def test_any_k_kernel_windows_chunks_and_thresholds(K):
+    """The any-K kernel through the checkpoint / rebuild layout (explicit chunk lengths that do and do not divide the
+    windows), windows whose scan ends before the decode window does, one- and two-site windows, ragged groups, with and
+    without segment ages, and a time threshold that puts the scan's state threshold beyond 256."""
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(64, 333, seed=K, cm_per_mb=25.0, switch_per_cm=0.6)
+    bits, derived, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    gen = (haps.cm / 100.0).astype(np.float32)
+    wins = [(0, 64, 0, 333, 0, 333), (64, 40, 3, 330, 3, 330), (104, 64, 10, 331, 37, 300), (168, 9, 100, 101, 100, 101),
+            (177, 33, 200, 202, 200, 202), (210, 64, 5, 222, 6, 221), (274, 20, 0, 49, 0, 49), (294, 64, 290, 333, 301, 333),
+            (358, 64, 0, 333, 100, 150)]
+    n = wins[-1][0] + wins[-1][1]
+    pairs = O.enumerate_all_pairs(32)[100:100 + n]
+    groups = np.zeros(len(wins), capi.GROUP_DTYPE)
+    for g, w in zip(groups, wins):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    for time, flags in ((200, capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP), (30000, 0), (30000, capi.FSMC_WANT_MAP)):
+        pm = O.prepare_model(tables, gen, haps.bp, derived, 64, time=time)
+        if time == 30000:
+            assert pm.state_threshold > 256
+        want = []
+        for first, cnt, frm, to, sfrm, sto in wins:
+            sub = pairs[first:first + cnt]
+            ob = np.stack([(folded[a] ^ folded[b])[frm:to] for a, b in sub])
+            hb = np.stack([(folded[a] & folded[b])[frm:to] for a, b in sub])
+            post, _ = O.decode_batch(pm, ob, hb, frm, to)
+            full = np.zeros((pm.S, pm.K, cnt), np.float32)
+            full[frm:to] = post[frm:to]
+            for v in range(cnt):
+                want.append(O.ibd_scan_pair(pm, full, v, sfrm, sto, pair_ordinal=first + v,
+                                            want_mean=bool(flags & capi.FSMC_WANT_MEAN),
+                                            want_map=bool(flags & capi.FSMC_WANT_MAP)))
+        want = np.concatenate(want)
+        assert want.size > 10
+        for chunk in (0, 48, 37):
+            ctx = capi.Context(0)
+            model = ctx.create_model(pm)
+            ctx.upload_haps(bits, pm.S)
+            if chunk:
+                ctx.set_chunk_sites(chunk)
+            got = ctx.decode_ibd(model, pr, groups, flags)
+            assert ctx.last_kernel() == 0 and (ctx.info()["max_chunks"] > 1) == bool(chunk)
+            ctx.close()
+            assert got.size == want.size
+            for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"),
+                                  ("post_mean", "postMean"), ("map", "map")):
+                np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f"{f_got} time {time} chunk {chunk}")
 
 
 def test_mis_shaped_model_arrays_are_rejected_before_the_c_call():
