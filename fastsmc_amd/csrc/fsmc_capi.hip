@@ -490,6 +490,11 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   if (blocksPerCU > 8) {
     blocksPerCU = 8;
   }
+  if (anyStates(m) && blocksPerCU > 4) {
+    // the any-K kernel streams its K-vectors through the caches: with four waves per CU more of them stay there
+    // (600 x 3000 list, K = 300: 1 / 2 / 4 / 8 waves per CU run 10.3 / 6.9 / 5.0 / 6.5 s)
+    blocksPerCU = 4;
+  }
   if (const char* cap = std::getenv("FSMC_DIAG_WAVES_PER_CU")) { // occupancy experiments only
     const int v = std::atoi(cap);
     if (v >= 1 && v < blocksPerCU) {
