@@ -26,7 +26,7 @@ echo "family done"
 cp $(find $OUT/identify_trace -name "*kernel_stats.csv" | head -1) $OUT/identify_kernel_stats.csv 2>/dev/null
 python3 tools/measure_configs.py hashing > $OUT/hashing.json 2> $OUT/hashing.err
 python3 tools/measure_configs.py seq seq100 > $OUT/sequence.jsonl 2> $OUT/sequence.err
-python3 tools/measure_configs.py k256 k192 > $OUT/wide_w2.jsonl 2> $OUT/wide_w2.err
+python3 tools/measure_configs.py k256 k192 k300 > $OUT/wide_w2.jsonl 2> $OUT/wide_w2.err
 echo "identify done"
 python3 tools/measure_configs.py run_c2 > $OUT/run_c2.json 2> $OUT/run_c2.err
 python3 tools/measure_configs.py c1 > $OUT/c1.json 2> $OUT/c1.err
