@@ -514,7 +514,8 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   }
   // float4 per lane of a stored K-vector: a padded family member (and the wave-group kernel) stores its ghosts too
   const int member = familyMember(m);
-  const size_t K4 = w2 ? (size_t)m->KP / 4 : (size_t)((member > 0 ? member : m->K) + 3) / 4;
+  // (the any-K kernel's rows carry their scale in one more float4)
+  const size_t K4 = w2 ? (size_t)m->KP / 4 : (size_t)((member > 0 ? member : m->K) + 3) / 4 + (anyStates(m) ? 1 : 0);
   const size_t vecBytes = K4 * kWave * sizeof(float4);
   const WsBudget budget = workspaceBudget(ctx, ws ? *ws : ctx->ws);
   const uint64_t limit = budget.hard / share;

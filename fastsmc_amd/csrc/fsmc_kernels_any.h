@@ -19,8 +19,8 @@
 namespace fsmc
 {
 
-constexpr int kAnyExtraRows = 10; // per wave, beside the chunk buffer and the checkpoints: alpha (2), beta (2),
-                                  // temporaries (2), posterior, per-state sums of open segments, the half-step (SEQ)
+constexpr int kAnyExtraRows = 9;  // per wave, beside the chunk buffer and the checkpoints: alpha (2), beta (2),
+                                  // a temporary, alpha*beta, per-state sums of open segments, the half-step (SEQ)
 
 __device__ __forceinline__ float4 anyLd(const float4* row, const int k4, const int lane)
 {
@@ -34,43 +34,44 @@ __device__ __forceinline__ float& anyAt(float4& v, const int i)
 {
   return reinterpret_cast<float*>(&v)[i];
 }
-
-// sum over the states, k ascending from 0.f; 1.0f / sum; multiply (HmmUtils.cpp:102-151)
-__device__ __forceinline__ void anyScale(float4* row, const int K, const int lane)
+__device__ __forceinline__ float anyGet(const float4& v, const int i)
 {
-  const int K4 = (K + 3) >> 2;
-  float sum = 0.f;
-  for (int k4 = 0; k4 < K4; ++k4) {
-    float4 v = anyLd(row, k4, lane);
-    for (int i = 0; i < 4 && 4 * k4 + i < K; ++i) {
-      sum = sum + anyAt(v, i);
-    }
-  }
-  const float sc = 1.0f / sum;
-  for (int k4 = 0; k4 < K4; ++k4) {
-    float4 v = anyLd(row, k4, lane);
-    for (int i = 0; i < 4; ++i) {
-      anyAt(v, i) = (4 * k4 + i < K) ? anyAt(v, i) * sc : 0.f;
-    }
-    anySt(row, k4, lane, v);
+  return reinterpret_cast<const float*>(&v)[i];
+}
+// A row is K4 float4 of values and one more float4 whose first float is the row's SCALE: the vector the row stands for
+// is value * scale.  The reference scales a vector right after it computes it (sum over the states, 1.0f / sum, multiply:
+// HmmUtils.cpp:102-151); here the multiply happens when the row is read -- the same multiplication on the same bits -- and
+// a pass over the row in memory is saved (a step is HBM-bound on its own temporaries).  Un-normalised rows (the half-steps
+// of sequence mode) have scale 1.0f: x * 1.0f is exact.
+__device__ __forceinline__ float anyScaleOf(const float4* row, const int K4, const int lane)
+{
+  return anyLd(row, K4, lane).x;
+}
+__device__ __forceinline__ void anySetScale(float4* row, const int K4, const int lane, const float sc)
+{
+  anySt(row, K4, lane, make_float4(sc, 0.f, 0.f, 0.f));
+}
+__device__ __forceinline__ void anyCopy(float4* dst, const float4* src, const int K4, const int lane)
+{
+  for (int k4 = 0; k4 <= K4; ++k4) {
+    anySt(dst, k4, lane, anyLd(src, k4, lane));
   }
 }
 
-// HMM::getPreviousBetaBatched (HMM.cpp:943-1016): out = the un-normalised beta of the site before `last`'s.
-// e: this lane's emission row of last's site ([KP/4] float4); D, B, U, RR: the step's table rows; vec, BU: temporaries.
+// HMM::getPreviousBetaBatched (HMM.cpp:943-1016) + the scaling sum: out = beta of the site before `last`'s, its values
+// un-scaled and its scale 1 / (sum over the states, k ascending from 0.f) -- or 1 when the step is not normalised.
+// e: this lane's emission row of last's site ([KP/4] float4); D, B, U, RR: the step's table rows; BU: temporary.
+// Two passes: down (vec = last*e on the fly, BU kept) and up (vec again -- the same products --, BL, the row, its sum).
 __device__ __forceinline__ void anyBetaStep(const int K, const float4* e, const float* D, const float* B, const float* U,
-                                            const float* RR, const float4* last, float4* out, float4* vec, float4* BU,
-                                            const int lane)
+                                            const float* RR, const float4* last, float4* out, float4* BU,
+                                            const bool normalise, const int lane)
 {
   const int K4 = (K + 3) >> 2;
-  for (int k4 = 0; k4 < K4; ++k4) { // vec = last * emission
-    const float4 l = anyLd(last, k4, lane), em = e[k4];
-    anySt(vec, k4, lane, make_float4(l.x * em.x, l.y * em.y, l.z * em.z, l.w * em.w));
-  }
+  const float scL = anyScaleOf(last, K4, lane);
   // BU[K-1] = 0, BU[k] = U[k]*vec[k+1] + RR[k]*BU[k+1], from the top down
   float buAbove = 0.f, vecAbove = 0.f;
   for (int k4 = K4 - 1; k4 >= 0; --k4) {
-    const float4 v = anyLd(vec, k4, lane);
+    const float4 l = anyLd(last, k4, lane), em = e[k4];
     float4 bu = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = 3; i >= 0; --i) {
       const int k = 4 * k4 + i;
@@ -81,37 +82,42 @@ __device__ __forceinline__ void anyBetaStep(const int K, const float4* e, const 
         }
         anyAt(bu, i) = x;
         buAbove = x;
-        vecAbove = reinterpret_cast<const float*>(&v)[i];
+        vecAbove = (anyGet(l, i) * scL) * anyGet(em, i);
       }
     }
     anySt(BU, k4, lane, bu);
   }
   // BL[k] = BL[k-1] + B[k-1]*vec[k-1];  out[k] = (BL + D[k]*vec[k]) + BU[k]
-  float BL = 0.f, vecBelow = 0.f;
+  float BL = 0.f, vecBelow = 0.f, sum = 0.f;
   for (int k4 = 0; k4 < K4; ++k4) {
-    const float4 v = anyLd(vec, k4, lane), bu = anyLd(BU, k4, lane);
+    const float4 l = anyLd(last, k4, lane), em = e[k4], bu = anyLd(BU, k4, lane);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = 0; i < 4; ++i) {
       const int k = 4 * k4 + i;
       if (k < K) {
-        const float vk = reinterpret_cast<const float*>(&v)[i];
+        const float vk = (anyGet(l, i) * scL) * anyGet(em, i);
         if (k) {
           BL = BL + B[k - 1] * vecBelow;
         }
-        anyAt(o, i) = BL + D[k] * vk + reinterpret_cast<const float*>(&bu)[i];
+        const float x = BL + D[k] * vk + anyGet(bu, i);
+        anyAt(o, i) = x;
+        sum = sum + x;
         vecBelow = vk;
       }
     }
     anySt(out, k4, lane, o);
   }
+  anySetScale(out, K4, lane, normalise ? 1.0f / sum : 1.0f);
 }
 
-// HMM::getNextAlphaBatched (HMM.cpp:787-830): out = the un-normalised alpha of the site after prev's.
-// e: this lane's emission row of the NEW site; aC: temporary (suffix sums of prev).
+// HMM::getNextAlphaBatched (HMM.cpp:787-830) + the scaling sum: out = alpha of the site after prev's (values un-scaled,
+// scale as above).  e: this lane's emission row of the NEW site; aC: temporary (suffix sums of prev).
 __device__ __forceinline__ void anyAlphaStep(const int K, const float4* e, const float* D, const float* B, const float* U,
-                                             const float* cR, const float4* prev, float4* out, float4* aC, const int lane)
+                                             const float* cR, const float4* prev, float4* out, float4* aC,
+                                             const bool normalise, const int lane)
 {
   const int K4 = (K + 3) >> 2;
+  const float scP = anyScaleOf(prev, K4, lane);
   // alphaC[K-1] = prev[K-1]; alphaC[k] = alphaC[k+1] + prev[k]
   float above = 0.f;
   for (int k4 = K4 - 1; k4 >= 0; --k4) {
@@ -120,7 +126,7 @@ __device__ __forceinline__ void anyAlphaStep(const int K, const float4* e, const
     for (int i = 3; i >= 0; --i) {
       const int k = 4 * k4 + i;
       if (k < K) {
-        const float pk = reinterpret_cast<const float*>(&pv)[i];
+        const float pk = anyGet(pv, i) * scP;
         const float x = (k == K - 1) ? pk : above + pk;
         anyAt(c, i) = x;
         above = x;
@@ -128,7 +134,7 @@ __device__ __forceinline__ void anyAlphaStep(const int K, const float4* e, const
     }
     anySt(aC, k4, lane, c);
   }
-  float AU = 0.f, prevBelow = 0.f;
+  float AU = 0.f, prevBelow = 0.f, sum = 0.f;
   for (int k4 = 0; k4 < K4; ++k4) {
     const float4 pv = anyLd(prev, k4, lane), c = anyLd(aC, k4, lane), em = e[k4];
     // alphaC[k+1] of this block's last state sits in the next block
@@ -137,21 +143,24 @@ __device__ __forceinline__ void anyAlphaStep(const int K, const float4* e, const
     for (int i = 0; i < 4; ++i) {
       const int k = 4 * k4 + i;
       if (k < K) {
-        const float pk = reinterpret_cast<const float*>(&pv)[i];
+        const float pk = anyGet(pv, i) * scP;
         if (k) {
           AU = U[k - 1] * prevBelow + cR[k - 1] * AU;
         }
         float term = AU + D[k] * pk;
         if (k < K - 1) {
-          const float cAbove = (i < 3) ? reinterpret_cast<const float*>(&c)[i + 1] : cNext.x;
+          const float cAbove = (i < 3) ? anyGet(c, i + 1) : cNext.x;
           term = term + B[k] * cAbove;
         }
-        anyAt(o, i) = reinterpret_cast<const float*>(&em)[i] * term;
+        const float x = anyGet(em, i) * term;
+        anyAt(o, i) = x;
+        sum = sum + x;
         prevBelow = pk;
       }
     }
     anySt(out, k4, lane, o);
   }
+  anySetScale(out, K4, lane, normalise ? 1.0f / sum : 1.0f);
 }
 
 template <int MODE, bool TRACK, bool SEQ>
@@ -162,20 +171,19 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
   const int K = p.K, KP = p.KP;
   const int K4 = (K + 3) >> 2, E4 = KP >> 2;
   constexpr int NC = SEQ ? 4 : 3;
-  const size_t vecF4 = (size_t)K4 * kWave;
+  const size_t vecF4 = (size_t)(K4 + 1) * kWave; // float4 per row: the values and the scale (the host plans K4 + 1)
   const int C = p.chunk;
   float4* const chunkbuf = p.ws + (size_t)blockIdx.x * p.wsSlot;
   float4* const ckpt = chunkbuf + (size_t)p.chunkRows * vecF4; // [maxChunks + 2]
   float4* const extra = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
   float4* const rowA0 = extra;             // alpha, two rows in turn
   float4* const rowA1 = extra + vecF4;
-  float4* const rowB0 = extra + 2 * vecF4; // beta of pass B, two rows in turn; the gap half-step's result (SEQ)
+  float4* const rowB0 = extra + 2 * vecF4; // beta of pass B, two rows in turn
   float4* const rowB1 = extra + 3 * vecF4;
-  float4* const tmp0 = extra + 4 * vecF4;  // vec / alphaC
-  float4* const tmp1 = extra + 5 * vecF4;  // BU
-  float4* const post = extra + 6 * vecF4;  // the normalised posterior of the current site
-  float4* const sps = extra + 7 * vecF4;   // per-state posterior sums of the open segment (TRACK)
-  float4* const half = extra + 8 * vecF4;  // SEQ: beta after the half-step across the gap
+  float4* const tmp = extra + 4 * vecF4;   // BU / alphaC of the step under way
+  float4* const post = extra + 5 * vecF4;  // alpha*beta of the current site; its scale slot holds 1 / (their sum)
+  float4* const sps = extra + 6 * vecF4;   // per-state posterior sums of the open segment (TRACK)
+  float4* const half = extra + 7 * vecF4;  // SEQ: beta after the half-step across the gap
   __shared__ unsigned char clsLds[kWave];
 
   for (unsigned round = 0;; ++round) {
@@ -216,33 +224,41 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
       return p.emis3 + ((size_t)q * NC + cls) * E4;
     };
     auto tableRow = [&](const float* t, const int row) -> const float* { return t + (size_t)row * KP; };
-    // beta of site pos from beta of site pos + 1 (scaled on both ends): last -> out (out != last)
-    auto betaInto = [&](const int pos, const float4* last, float4* out) {
-      const int q = pos + 1;
-      if constexpr (SEQ) {
-        // HMM.cpp:915-925: the half-step across the gap with the homozygous row, then the step out of site q
-        const int rg = p.rowGapB[q];
-        anyBetaStep(K, emisRow(q, 3), tableRow(p.D, rg), tableRow(p.B, rg), tableRow(p.U, rg), tableRow(p.RR, rg), last,
-                    half, tmp0, tmp1, lane);
-        const int rs = p.rowSiteB[q];
-        anyBetaStep(K, emisRow(q, obsClass(q)), tableRow(p.D, rs), tableRow(p.B, rs), tableRow(p.U, rs),
-                    tableRow(p.RR, rs), half, out, tmp0, tmp1, lane);
-      } else {
-        const int r = p.stepRow[q];
-        anyBetaStep(K, emisRow(q, obsClass(q)), tableRow(p.D, r), tableRow(p.B, r), tableRow(p.U, r), tableRow(p.RR, r),
-                    last, out, tmp0, tmp1, lane);
-      }
-      anyScale(out, K, lane);
+    // the half-step of sequence mode across the gap in front of site q, backward: un-normalised (HMM.cpp:915-919)
+    auto betaGap = [&](const int q, const float4* in, float4* out) {
+      const int rg = p.rowGapB[q];
+      anyBetaStep(K, emisRow(q, 3), tableRow(p.D, rg), tableRow(p.B, rg), tableRow(p.U, rg), tableRow(p.RR, rg), in, out,
+                  tmp, false, lane);
     };
-    auto betaInit = [&](float4* out) { // ones, scaled: K sequential adds, 1/K (HMM.cpp:887-897)
+    // the step out of site q, backward, normalised (array mode: THE step; sequence mode: behind the half-step)
+    auto betaSite = [&](const int q, const float4* in, float4* out) {
+      const int r = SEQ ? p.rowSiteB[q] : p.stepRow[q];
+      anyBetaStep(K, emisRow(q, obsClass(q)), tableRow(p.D, r), tableRow(p.B, r), tableRow(p.U, r), tableRow(p.RR, r), in,
+                  out, tmp, true, lane);
+    };
+    // beta of site pos from beta of site pos + 1: last -> out (out != last)
+    auto betaInto = [&](const int pos, const float4* last, float4* out) {
+      if constexpr (SEQ) {
+        betaGap(pos + 1, last, half);
+        betaSite(pos + 1, half, out);
+      } else {
+        betaSite(pos + 1, last, out);
+      }
+    };
+    auto betaInit = [&](float4* out) { // ones; scale 1 / (K sequential adds) (HMM.cpp:887-897)
+      float sum = 0.f;
       for (int k4 = 0; k4 < K4; ++k4) {
         float4 v;
         for (int i = 0; i < 4; ++i) {
-          anyAt(v, i) = (4 * k4 + i < K) ? 1.0f : 0.f;
+          const bool real = 4 * k4 + i < K;
+          anyAt(v, i) = real ? 1.0f : 0.f;
+          if (real) {
+            sum = sum + 1.0f;
+          }
         }
         anySt(out, k4, lane, v);
       }
-      anyScale(out, K, lane);
+      anySetScale(out, K4, lane, 1.0f / sum);
     };
 
     const int nA = aEnd - from;
@@ -264,9 +280,7 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
             slot = (pos - from) / C;
           }
           if (slot >= 0) {
-            for (int k4 = 0; k4 < K4; ++k4) {
-              anySt(ckpt + (size_t)slot * vecF4, k4, lane, anyLd(bCur, k4, lane));
-            }
+            anyCopy(ckpt + (size_t)slot * vecF4, bCur, K4, lane);
           }
           if (pos <= stop) {
             break;
@@ -289,53 +303,47 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
       const int hi = (lo + C < aEnd) ? lo + C : aEnd;
       // rebuild: the beta rows of sites lo .. hi-1 into the chunk buffer, from the window's end or from a checkpoint
       {
-        int pos;
-        const float4* last;
-        if (hi == to) {
-          float4* top = chunkbuf + (size_t)(to - 1 - lo) * vecF4;
-          betaInit(top);
-          last = top;
-          pos = to - 2;
-        } else {
-          last = ckpt + (size_t)(hi == aEnd ? nChunks : j + 1) * vecF4; // beta of site hi
-          pos = hi - 1;
+        const float4* start = nullptr; // beta of site hi, when the chain starts from a checkpoint
+        if (hi != to) {
+          start = ckpt + (size_t)(hi == aEnd ? nChunks : j + 1) * vecF4;
         }
         if constexpr (SEQ) {
           // What the reference's beta buffer holds for a site in sequence mode is beta AFTER the half-step across the gap
           // (lastComputedBeta = previousBeta copies it over the site's row, HMM.cpp:915-925) -- un-normalised; only the
-          // window's first site keeps its scaled beta.  The chunk buffer therefore keeps the half-step rows, and the
-          // chain runs  scaled beta[s] -> half-step (kept) -> step out of site s, scaled = beta[s-1].
-          float4* bs = rowB0; // scaled beta of the current site
+          // window's first site keeps its own beta.  The chunk buffer therefore keeps the half-step rows, and the chain
+          // runs  beta[s] -> half-step (kept) -> step out of site s = beta[s-1].
+          float4* bs = rowB0; // beta of the current site
           int s;
-          if (hi == to) {
-            for (int k4 = 0; k4 < K4; ++k4) {
-              anySt(bs, k4, lane, anyLd(last, k4, lane));
-            }
+          if (!start) {
+            betaInit(bs);
             s = to - 1;
           } else {
-            betaInto(hi - 1, last, bs); // (through site hi's half-step, which belongs to the next chunk)
+            betaInto(hi - 1, start, bs); // (through site hi's half-step, which belongs to the next chunk)
             s = hi - 1;
           }
           for (; s >= lo; --s) {
             float4* out = chunkbuf + (size_t)(s - lo) * vecF4;
             if (s == from) {
-              for (int k4 = 0; k4 < K4; ++k4) {
-                anySt(out, k4, lane, anyLd(bs, k4, lane));
-              }
+              anyCopy(out, bs, K4, lane);
               break;
             }
-            const int rg = p.rowGapB[s];
-            anyBetaStep(K, emisRow(s, 3), tableRow(p.D, rg), tableRow(p.B, rg), tableRow(p.U, rg), tableRow(p.RR, rg), bs,
-                        out, tmp0, tmp1, lane);
+            betaGap(s, bs, out);
             if (s > lo) {
-              const int rs = p.rowSiteB[s];
-              anyBetaStep(K, emisRow(s, obsClass(s)), tableRow(p.D, rs), tableRow(p.B, rs), tableRow(p.U, rs),
-                          tableRow(p.RR, rs), out, bs, tmp0, tmp1, lane);
-              anyScale(bs, K, lane);
+              betaSite(s, out, bs);
             }
           }
-          (void)pos;
         } else {
+          int pos;
+          const float4* last;
+          if (!start) {
+            float4* top = chunkbuf + (size_t)(to - 1 - lo) * vecF4;
+            betaInit(top);
+            last = top;
+            pos = to - 2;
+          } else {
+            last = start;
+            pos = hi - 1;
+          }
           for (; pos >= lo; --pos) {
             float4* out = chunkbuf + (size_t)(pos - lo) * vecF4;
             betaInto(pos, last, out);
@@ -347,30 +355,31 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
       for (int pos = lo; pos < hi; ++pos) {
         const int c = obsClass(pos);
         if (pos == from) {
-          // alpha of the window's first site: pi * emission, scaled (HMM.cpp:736-747)
+          // alpha of the window's first site: pi * emission; scale 1 / sum (HMM.cpp:736-747)
           const float4* e = emisRow(pos, c);
+          float sum = 0.f;
           for (int k4 = 0; k4 < K4; ++k4) {
             const float4 em = e[k4];
             float4 v;
             for (int i = 0; i < 4; ++i) {
               const int k = 4 * k4 + i;
-              anyAt(v, i) = (k < K) ? p.pi[k] * reinterpret_cast<const float*>(&em)[i] : 0.f;
+              anyAt(v, i) = (k < K) ? p.pi[k] * anyGet(em, i) : 0.f;
+              if (k < K) {
+                sum = sum + anyAt(v, i);
+              }
             }
             anySt(aCur, k4, lane, v);
           }
-          anyScale(aCur, K, lane);
+          anySetScale(aCur, K4, lane, 1.0f / sum);
         } else {
+          const int r = p.stepRow[pos]; // (sequence mode: the site step; aNxt holds alpha of site pos - 1 after the
+                                        //  half-step across the gap, computed at that site, below)
           if constexpr (SEQ) {
-            // (aNxt holds alpha of site pos - 1 after the half-step across the gap: computed at that site, below)
-            const int rs = p.stepRow[pos];
-            anyAlphaStep(K, emisRow(pos, c), tableRow(p.D, rs), tableRow(p.B, rs), tableRow(p.U, rs), p.cR, aNxt, aCur,
-                         tmp0, lane);
-            anyScale(aCur, K, lane);
+            anyAlphaStep(K, emisRow(pos, c), tableRow(p.D, r), tableRow(p.B, r), tableRow(p.U, r), p.cR, aNxt, aCur, tmp,
+                         true, lane);
           } else {
-            const int r = p.stepRow[pos];
-            anyAlphaStep(K, emisRow(pos, c), tableRow(p.D, r), tableRow(p.B, r), tableRow(p.U, r), p.cR, aCur, aNxt, tmp0,
-                         lane);
-            anyScale(aNxt, K, lane);
+            anyAlphaStep(K, emisRow(pos, c), tableRow(p.D, r), tableRow(p.B, r), tableRow(p.U, r), p.cR, aCur, aNxt, tmp,
+                         true, lane);
             float4* t = aCur;
             aCur = aNxt;
             aNxt = t;
@@ -384,36 +393,32 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
           if (pos < to - 1) {
             const int rg = p.rowGapF[pos + 1];
             anyAlphaStep(K, emisRow(pos + 1, 3), tableRow(p.D, rg), tableRow(p.B, rg), tableRow(p.U, rg), p.cR, aCur, aNxt,
-                         tmp0, lane);
+                         tmp, false, lane);
             aUse = aNxt;
           }
         }
-        // combine with beta of this site and normalise (HMM.cpp:669-692)
+        // combine with beta of this site and normalise (HMM.cpp:669-692): post = alpha*beta, its scale 1 / sum
         const float4* bRow = chunkbuf + (size_t)(pos - lo) * vecF4;
+        const float scA = anyScaleOf(aUse, K4, lane), scB = anyScaleOf(bRow, K4, lane);
         float sumq = 0.f;
         for (int k4 = 0; k4 < K4; ++k4) {
           const float4 a = anyLd(aUse, k4, lane), b = anyLd(bRow, k4, lane);
-          float4 q = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
           for (int i = 0; i < 4 && 4 * k4 + i < K; ++i) {
-            sumq = sumq + anyAt(q, i);
+            const float x = (anyGet(a, i) * scA) * (anyGet(b, i) * scB);
+            anyAt(q, i) = x;
+            sumq = sumq + x;
           }
           anySt(post, k4, lane, q);
         }
         const float cq = 1.0f / sumq;
-        for (int k4 = 0; k4 < K4; ++k4) {
-          float4 q = anyLd(post, k4, lane);
-          for (int i = 0; i < 4; ++i) {
-            anyAt(q, i) = (4 * k4 + i < K) ? anyAt(q, i) * cq : 0.f;
-          }
-          anySt(post, k4, lane, q);
-        }
 
         if (MODE == kModeDump) {
           float* out = p.dumpOut + p.dumpOffsets[g] + (size_t)(pos - from) * K * kWave + lane;
           for (int k4 = 0; k4 < K4; ++k4) {
             const float4 q = anyLd(post, k4, lane);
             for (int i = 0; i < 4 && 4 * k4 + i < K; ++i) {
-              out[(size_t)(4 * k4 + i) * kWave] = valid ? reinterpret_cast<const float*>(&q)[i] : 0.f;
+              out[(size_t)(4 * k4 + i) * kWave] = valid ? anyGet(q, i) * cq : 0.f;
             }
           }
         }
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
           for (int k4 = 0; k4 < K4; ++k4) {
             const float4 q = anyLd(post, k4, lane);
             for (int i = 0; i < 4 && 4 * k4 + i < K; ++i) {
-              const float pk = reinterpret_cast<const float*>(&q)[i];
+              const float pk = anyGet(q, i) * cq;
               mean = mean + pk * p.expCoal[4 * k4 + i];
               if (best < pk) {
                 arg = 4 * k4 + i;
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
         if (MODE == kModeSums) {
           // HMM::augmentSumOverPairs (HMM.cpp:1052-1081): per site and state the batch's posteriors summed over its pairs
           // in batch order; lane j takes the states j, j + 64, ... and reads the pairs' values from the posterior row
+          anySetScale(post, K4, lane, cq);
           clsLds[lane] = (unsigned char)c;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_s_barrier();
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
               }
             }
             for (int v = 0; v < nPairsInGroup; ++v) {
-              const float q = pf[((size_t)(kk >> 2) * kWave + v) * 4 + (kk & 3)];
+              const float q = pf[((size_t)(kk >> 2) * kWave + v) * 4 + (kk & 3)] * pf[((size_t)K4 * kWave + v) * 4];
               s = s + q;
               if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
                 const int cv = clsLds[v];
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
           for (int k4 = 0; 4 * k4 < (int)nSum; ++k4) {
             const float4 q = anyLd(post, k4, lane);
             for (int i = 0; i < 4 && 4 * k4 + i < (int)nSum; ++i) {
-              s = s + reinterpret_cast<const float*>(&q)[i];
+              s = s + anyGet(q, i) * cq;
             }
           }
           const int level = s >= p.thr[0] ? 0 : s >= p.thr[1] ? 1 : s >= p.thr[2] ? 2 : s >= p.thr[3] ? 3 : 4;
@@ -521,10 +527,10 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
               for (int k4 = 0; 4 * k4 < (int)p.ageThr && k4 < K4; ++k4) {
                 const float4 q = anyLd(post, k4, lane);
                 float4 sv = opening ? make_float4(0.f, 0.f, 0.f, 0.f) : anyLd(sps, k4, lane);
-                sv.x = sv.x + q.x;
-                sv.y = sv.y + q.y;
-                sv.z = sv.z + q.z;
-                sv.w = sv.w + q.w;
+                sv.x = sv.x + q.x * cq;
+                sv.y = sv.y + q.y * cq;
+                sv.z = sv.z + q.z * cq;
+                sv.w = sv.w + q.w * cq;
                 anySt(sps, k4, lane, sv);
               }
             }
