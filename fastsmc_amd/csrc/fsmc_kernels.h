@@ -1134,6 +1134,13 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
     const int nA = aEnd - from;
     const int nChunks = (nA + C - 1) / C;
     const bool single = nChunks <= 1;
+    // Wave priority = how much of its group a wave still has in front of it.  Left alone, the two waves of a SIMD do not
+    // share it evenly: the older one is served first and runs its groups in half the time of its partner (C3 windows:
+    // 0.7 s against 1.4 s a group, per-group stamps of a diagnostic build) -- the same throughput while the queue is full,
+    // but when it runs dry the favoured wave is done early and its partner finishes alone, on a SIMD that a lone wave
+    // does not fill.  With the wave that has MORE left in front the two finish together: 4096 groups of the C3 shape (what
+    // each of four GPUs gets) 2291 -> 1927 ms, 2048 groups 1023 -> 980, C2 1827 -> 1810 (same box).
+    __builtin_amdgcn_s_setprio(3); // a fresh group: everything remains (pass B is about a third of it)
 
     int wordIdx = -1;
     unsigned long long xw = 0, aw = 0;
@@ -1428,6 +1435,17 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
     };
 
     for (int j = 0; j < (nChunks > 0 ? nChunks : 0); ++j) {
+      {
+        // (two thirds of the work are left when pass A starts: levels 2, 1, 0 as the chunks go by)
+        const int left = (8 * (nChunks - j)) / (3 * nChunks);
+        if (left >= 2) {
+          __builtin_amdgcn_s_setprio(2);
+        } else if (left == 1) {
+          __builtin_amdgcn_s_setprio(1);
+        } else {
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
       const int lo = from + j * C;
       const int hi = (lo + C < aEnd) ? lo + C : aEnd;
       // the rows of this chunk: kept by pass B (a resident chunk), or rebuilt below into the wave's chunk buffer
