@@ -1070,6 +1070,9 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   };
 
   for (unsigned round = 0;; ++round) {
+#if defined(FSMC_DIAG_GROUP_TIMES)
+    const unsigned long long diagT0 = __builtin_amdgcn_s_memrealtime();
+#endif
     unsigned g = 0;
     if (MODE == kModeSums) {
       // one BATCH per wave and launch: wave i writes the sums of batch groupBase + i into plane i, and the host adds the
@@ -1937,6 +1940,26 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         atomicAdd(&p.phaseCycles[8 + r], (unsigned long long)cycW.acc[r]);
+      }
+    }
+#endif
+#if defined(FSMC_DIAG_GROUP_TIMES)
+    // diagnostic builds (tools/build_variant.sh <name> -DFSMC_DIAG_GROUP_TIMES; tools/analyse_group_times.py): one marker
+    // record per group -- start = -1, end = the wave's slot, prob / post_mean = when the group ended / began (ms of the
+    // 100 MHz clock), map = HW_ID and XCC_ID -- among the IBD records.  How the SIMD-sharing of the waves was found.
+    if (MODE == kModeIbd && lane == 0) {
+      const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned idx = atomicAdd(&p.counters[1], 1u);
+      if (idx < p.recCap) {
+        fsmc_ibd_record r;
+        r.pair = pairIdx;
+        r.start = -1;
+        r.end = (int)blockIdx.x;
+        r.prob = (float)((double)(t1 & 0xFFFFFFFFull) / 1e5);
+        r.post_mean = (float)((double)(diagT0 & 0xFFFFFFFFull) / 1e5);
+        r.map = __int_as_float((int)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) |
+                               (int)((__builtin_amdgcn_s_getreg(63508) & 0xFu) << 16));
+        p.recs[idx] = r;
       }
     }
 #endif

@@ -1,3 +1,8 @@
+"""Per-group begin / end times of a decode, from the marker records of a diagnostic build:
+  tools/build_variant.sh grouptimes -DFSMC_DIAG_GROUP_TIMES
+  FSMC_HIP_LIB=fastsmc_amd/variants/libgrouptimes.so python bench.py --workload c3 --pairs 262144 --dump-records r.npy
+  python tools/analyse_group_times.py r.npy
+Prints the spread of the groups' durations, when they ended, how many groups each resident wave took, per XCD."""
 import numpy as np, sys
 r=np.load(sys.argv[1])
 m=r[r["start"]==-1]
