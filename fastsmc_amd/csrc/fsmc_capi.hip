@@ -531,8 +531,8 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   // A window stays whole if that fits what the launches have earned (or is no longer than a chunk would be anyway; a
   // paired launch only has this layout and was planned within the same budget).
   // (an explicit chunk length is kept, except for paired launches)
-  if (chunkRows(L) + sideRows + 1 <= rowsAvail && (chunkRows(L) + sideRows + 1 <= rowsSoft || L <= defaultChunk || paired) &&
-      !(ctx->chunkSites && ctx->chunkSites < L && !paired)) {
+  if (chunkRows(L) + sideRows + 1 <= rowsAvail && (chunkRows(L) + sideRows + 1 <= rowsSoft || L <= defaultChunk) &&
+      !(ctx->chunkSites && ctx->chunkSites < L)) {
     C = L;
     maxChunks = 1;
   } else {
@@ -1277,17 +1277,8 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   uint64_t maxLen = 0, maxLenAlone = 0; // pairing budgets: beside a second kernel (half the workspace) / on its own
   if (ctx->pairing != 0 && !m->sequence && familyMember(m) > 0) {
     fnDual = pickKernel(kModeIbd, track, m, true);
-    int blocksPerCU = 0;
-    FSMC_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fnDual, kWave, 0));
-    // (no more waves than groups: a short list leaves each of them more of the budget)
-    const size_t slots = std::max<size_t>(
-        1, std::min<size_t>((size_t)ctx->nCU * std::min(std::max(blocksPerCU, 1), 8), ctx->hGroups.size()));
-    const size_t vecBytes = (size_t)(familyMember(m) + 3) / 4 * kWave * sizeof(float4);
-    const uint64_t limit = workspaceBudget(ctx, ctx->ws).soft / 2;
-    const size_t rowsAvail = (size_t)(limit / (vecBytes * slots));
-    const bool halfDual = halfAvailable(kModeIbd, m) && ctx->betaStride != 1; // a stored row serves two sites
-    maxLen = rowsAvail > 16 ? std::min<size_t>((rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
-    maxLenAlone = 2 * rowsAvail > 16 ? std::min<size_t>((2 * rowsAvail - 6) * (halfDual ? 2 : 1) - 1, 1u << 30) : 0;
+    // (the paired kernel has the chunked layout too: how long a window may be is no longer a question of memory)
+    maxLen = maxLenAlone = 1u << 30;
   }
   fsmc_ctx::IbdQueues& q = ctx->q;
   if (!q.valid || q.serial != ctx->worklistSerial || q.maxLen != maxLen || q.maxLenAlone != maxLenAlone ||
@@ -1337,9 +1328,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     if (rc != FSMC_OK) {
       return rc;
     }
-    if (planDual.maxChunks != 1) {
-      return fail(ctx, FSMC_ESTATE, "paired launch does not fit the single-chunk layout");
-    }
+
   }
   KernelFn fn = pickKernel(kModeIbd, track, m, false); // (after the paired pick: last_kernel / last_beta_stride name this one)
   if (haveRest) {

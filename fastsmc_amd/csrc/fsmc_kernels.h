@@ -1488,9 +1488,26 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
           if (pos >= lo) {
             stageEmis(pos + 1);
           }
+          // DUAL: the lanes whose own window ends at site q start from beta = 1 there, as in pass B (HMM.cpp:887-897)
+          auto reopenBeta = [&](const int q) {
+            if constexpr (DUAL) {
+              if (q == toA - 1 || q == toB - 1) {
+                const bool sel = myTo - 1 == q;
+                float ones = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  const float one = (!kGhost<KT> || k < p.K) ? 1.0f : 0.f;
+                  w[k] = sel ? one : w[k];
+                  ones = ones + one;
+                }
+                bsum = sel ? ones : bsum;
+              }
+            }
+          };
           bool stored = false;
           for (; pos >= lo; --pos) {
             const int q = pos + 1;
+            reopenBeta(q);
             waitEmisRows(stored); // the rows of site q have landed
             __builtin_amdgcn_wave_barrier();
             if (pos - 1 >= lo) {
@@ -1508,6 +1525,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             FSMC_END(cycW, 1);
             bsum = beta_core_pk<KT, KA, kGhost<KT>>(b, w, ops, rs, e, tabs.ghostMask, cycW);
           }
+          reopenBeta(pos + 1);
           scale_pk<KT, KA>(b, w, bsum);
           if (pos + 1 < hi) {
             storeRow(pos + 1, b);

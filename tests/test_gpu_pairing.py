@@ -102,13 +102,14 @@ def test_pairing_in_the_padded_members(K):
         np.testing.assert_array_equal(paired[f_got], want[f_want], err_msg=f_got)
 
 
-def test_windows_too_long_to_pair_run_in_the_second_kernel(small_problem):
-    """With a small workspace the long windows exceed the paired kernel's single-chunk budget: they go to the second
-    kernel while the short ones still pair."""
+def test_long_windows_pair_up_in_the_chunked_layout(small_problem):
+    """With a small workspace the long windows do not fit a wave whole: the paired kernel then decodes them in chunks
+    (checkpoints, rebuild pass -- the lanes of the half whose window ends inside a chunk start from beta = 1 there in
+    the rebuild as in the backward pass), two groups to a wave all the same."""
     pm, folded, S = small_problem["model"], small_problem["folded"], small_problem["model"].S
     allp = O.enumerate_all_pairs(32)
     shapes = [(32, 0, S, 0, S), (32, 100, 180, 100, 180), (32, 110, 190, 110, 190), (20, 5, S - 3, 10, S - 3),
-              (32, 400, 470, 400, 470), (32, 402, 480, 402, 480), (32, 0, S, 50, 600)]
+              (32, 400, 470, 400, 470), (32, 402, 480, 402, 480), (32, 0, S, 50, 600), (32, 30, S - 40, 30, S - 41)]
     wins, first = [], 0
     for cnt, frm, to, sf, st in shapes:
         wins.append((first, cnt, frm, to, sf, st))
@@ -118,14 +119,15 @@ def test_windows_too_long_to_pair_run_in_the_second_kernel(small_problem):
     ctx = capi.Context(0)
     model = ctx.create_model(pm)
     ctx.upload_haps(small_problem["bits"], S)
-    # the pairing budget is what the resident waves could hold -- no more waves than groups: ~200 rows of 18 float4 x 64
-    # lanes for each of the seven (half of that beside a second kernel) -- with beta stride 2 enough for windows of up to
-    # 387 sites, not for the 640-site ones
+    # ~200 rows of 18 float4 x 64 lanes for each wave: with beta stride 2 enough for windows of up to 387 sites whole, not
+    # for the 600-site ones
     ctx.set_workspace_limit(200 * 18 * 64 * 16 * len(shapes))
+    ctx.set_chunk_sites(96)
     plain, n0 = _run(ctx, model, pairs, wins, flags, pairing=0)
     paired, n1 = _run(ctx, model, pairs, wins, flags, pairing=1)
+    chunks = ctx.info()["max_chunks"]
     ctx.close()
-    assert n0 == 0 and n1 == 2
+    assert n0 == 0 and n1 == 4 and chunks > 1
     assert paired.tobytes() == plain.tobytes()
     want = _oracle(pm, folded, pairs, wins, True, True)
     assert paired.size == want.size
