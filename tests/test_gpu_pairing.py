@@ -1,10 +1,10 @@
 """Two half-groups per wavefront (decode_kernel<..., DUAL>; fsmc_ctx_set_pairing): hashing-mode batches of at most 32
 pairs share a wave, each lane decoded over its OWN group's decode and scan windows.  The records must be the bytes of
 the unpaired run (and of the oracle): different windows in the two halves, a half that starts later / ends earlier than
-the other, one-site windows, ragged halves, segment ages on and off, several family members, both beta strides.  Groups that do not pair
-(more than 32 pairs, or a window too long for the paired kernel's single-chunk layout) run in a second kernel of the
-same decode and land in the same record list; half-full groups that find no partner but fit ride in the paired kernel as
-items of their own."""
+the other, one-site windows, ragged halves, segment ages on and off, several family members, both beta strides, windows
+too long for a wave's workspace (the paired kernel then decodes them in chunks).  Groups that do not pair (more than 32
+pairs) run in a second kernel of the same decode and land in the same record list; half-full groups that find no partner
+ride in the paired kernel as items of their own."""
 import numpy as np
 import pytest
 
