@@ -1807,36 +1807,66 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (int kk = lane; kk < Kreal; kk += kWave) {
-            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + kk;
-            float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
+          // two states a lane in one walk over the pairs (K = 69: the five states beyond the first 64 ride along in lanes
+          // 0..4 instead of costing a second walk); every state's sum still adds its pairs in batch order
+          for (int kb = 0; kb < Kreal; kb += 2 * kWave) {
+            const int kk0 = kb + lane, kk1 = kb + kWave + lane;
+            const bool h0 = kk0 < Kreal, h1 = kk1 < Kreal;
+            float* const acc0 = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + (h0 ? kk0 : 0);
+            float* const acc1 = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + (h1 ? kk1 : 0);
+            float s[2] = {0.f, 0.f}, s00[2] = {0.f, 0.f}, s01[2] = {0.f, 0.f}, s11[2] = {0.f, 0.f};
             if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
-              if (p.flags & FSMC_WANT_SUMS) s = acc[0];
-              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                s00 = acc[p.sumsPlane];
-                s01 = acc[2 * p.sumsPlane];
-                s11 = acc[3 * p.sumsPlane];
+              if (p.flags & FSMC_WANT_SUMS) {
+                if (h0) s[0] = acc0[0];
+                if (h1) s[1] = acc1[0];
               }
-            }
-            for (int v = 0; v < nPairsInGroup; ++v) {
-              const float q = tile[kk * 65 + v];
-              s = s + q;
               if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                const int cv = cls[v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
-                if (cv == 2) {
-                  s11 = s11 + q;
-                } else if (cv == 1) {
-                  s00 = s00 + q;
-                } else {
-                  s01 = s01 + q;
+                if (h0) {
+                  s00[0] = acc0[p.sumsPlane];
+                  s01[0] = acc0[2 * p.sumsPlane];
+                  s11[0] = acc0[3 * p.sumsPlane];
+                }
+                if (h1) {
+                  s00[1] = acc1[p.sumsPlane];
+                  s01[1] = acc1[2 * p.sumsPlane];
+                  s11[1] = acc1[3 * p.sumsPlane];
                 }
               }
             }
-            if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
+            const int t0 = (h0 ? kk0 : 0) * 65, t1 = (h1 ? kk1 : 0) * 65;
+            for (int v = 0; v < nPairsInGroup; ++v) {
+              const float q0 = tile[t0 + v], q1 = tile[t1 + v];
+              s[0] = s[0] + q0;
+              s[1] = s[1] + q1;
+              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                const int cv = cls[v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
+                if (cv == 2) {
+                  s11[0] = s11[0] + q0;
+                  s11[1] = s11[1] + q1;
+                } else if (cv == 1) {
+                  s00[0] = s00[0] + q0;
+                  s00[1] = s00[1] + q1;
+                } else {
+                  s01[0] = s01[0] + q0;
+                  s01[1] = s01[1] + q1;
+                }
+              }
+            }
+            if (p.flags & FSMC_WANT_SUMS) {
+              if (h0) acc0[0] = s[0];
+              if (h1) acc1[0] = s[1];
+            }
             if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-              acc[p.sumsPlane] = s00;
-              acc[2 * p.sumsPlane] = s01;
-              acc[3 * p.sumsPlane] = s11;
+              if (h0) {
+                acc0[p.sumsPlane] = s00[0];
+                acc0[2 * p.sumsPlane] = s01[0];
+                acc0[3 * p.sumsPlane] = s11[0];
+              }
+              if (h1) {
+                acc1[p.sumsPlane] = s00[1];
+                acc1[2 * p.sumsPlane] = s01[1];
+                acc1[3 * p.sumsPlane] = s11[1];
+              }
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
