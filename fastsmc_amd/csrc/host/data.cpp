@@ -806,22 +806,45 @@ Data Data::fromArrays(const uint8_t* alleles, size_t nHaps, size_t nSites, const
   d.allocateBits();
   d.totalSamplesCount.assign(nSites, static_cast<int>(nHaps));
   d.derivedAlleleCounts.assign(nSites, 0);
-  for (size_t s = 0; s < nSites; ++s) {
-    d.addMarker(static_cast<unsigned long>(bp[s]), cm[s], static_cast<unsigned>(s));
-    int DAcount = 0;
+  // The input is haplotype-major: both passes walk it along its rows, on every host thread (a walk down the columns --
+  // one cache line per allele -- took 16 s for 10 000 haplotypes x 100 000 sites; this takes under one).
+  // pass 1: derived-allele count of every site, a block of 4096 sites per work item
+  constexpr size_t kSiteBlock = 4096;
+  const size_t nBlocks = (nSites + kSiteBlock - 1) / kSiteBlock;
+  std::vector<int> count(nSites, 0);
+  parallelFor(nBlocks, [&](size_t b) {
+    const size_t s0 = b * kSiteBlock, s1 = std::min(nSites, s0 + kSiteBlock);
+    int* c = count.data();
     for (size_t h = 0; h < nHaps; ++h) {
-      DAcount += alleles[h * nSites + s] ? 1 : 0;
-    }
-    const int total = static_cast<int>(nHaps);
-    const bool minorAlleleValue = foldToMinor ? (DAcount <= total - DAcount) : true;
-    d.siteWasFlippedDuringFolding[s] = !minorAlleleValue;
-    for (size_t h = 0; h < nHaps; ++h) {
-      if ((alleles[h * nSites + s] != 0) == minorAlleleValue) {
-        d.setBit(h, s);
+      const uint8_t* row = alleles + h * nSites;
+      for (size_t s = s0; s < s1; ++s) {
+        c[s] += row[s] ? 1 : 0;
       }
     }
+  });
+  const int total = static_cast<int>(nHaps);
+  std::vector<uint8_t> minorValue(nSites, 1); // the allele value stored as 1 (the minor allele when folding)
+  for (size_t s = 0; s < nSites; ++s) {
+    d.addMarker(static_cast<unsigned long>(bp[s]), cm[s], static_cast<unsigned>(s));
+    const int DAcount = count[s];
+    const bool minorAlleleValue = foldToMinor ? (DAcount <= total - DAcount) : true;
+    d.siteWasFlippedDuringFolding[s] = !minorAlleleValue;
+    minorValue[s] = minorAlleleValue ? 1 : 0;
     d.derivedAlleleCounts[s] = foldToMinor ? std::min(DAcount, total - DAcount) : DAcount;
   }
+  // pass 2: a haplotype's row of words, 64 sites to a word
+  parallelFor(nHaps, [&](size_t h) {
+    const uint8_t* row = alleles + h * nSites;
+    uint64_t* out = d.bits.data() + h * d.wordsPerHap;
+    for (size_t w = 0; w * 64 < nSites; ++w) {
+      const size_t s0 = w * 64, n = std::min<size_t>(64, nSites - s0);
+      uint64_t word = 0;
+      for (size_t i = 0; i < n; ++i) {
+        word |= static_cast<uint64_t>((row[s0 + i] != 0) == (minorValue[s0 + i] != 0)) << i;
+      }
+      out[w] = word;
+    }
+  });
   return d;
 }
 

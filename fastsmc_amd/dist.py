@@ -69,23 +69,18 @@ def sample_pair_ordinals(n_individuals: int, n_pairs: int, seed: int) -> np.ndar
     return got[keep]
 
 
-def gather_ibd_records(rec: np.ndarray, pair_offset: int, dist, rank: int, world: int, device="cpu"):
-    """Gather every rank's IBD records (structured array with a ``pair`` field holding *local* pair indices) to
-    rank 0: all_gather of counts, then gather of padded byte payloads.  Returns (total_count, records_or_None);
-    on rank 0 the records carry global pair indices and are ordered like a single-device run."""
+def _gather_records(local: np.ndarray, dist, rank: int, world: int, device):
+    """The path's one exchange: ``all_gather`` of the per-rank record counts, then ``gather`` of the byte payloads
+    padded to the longest one, to rank 0 (~34 B a record: latency-bound, topology irrelevant).  Returns
+    (total_count, concatenation in rank order on rank 0 / None elsewhere)."""
     import torch
 
-    local = rec.copy()
-    local["pair"] += np.uint32(pair_offset)
-    if dist is None or world == 1:
-        return int(local.size), local
     cnt = torch.tensor([local.size], device=device, dtype=torch.int64)
     counts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(counts, cnt)
     counts = [int(c.item()) for c in counts]
-    mx = max(counts)
     item = local.dtype.itemsize
-    payload = torch.zeros(max(mx, 1) * item, dtype=torch.uint8, device=device)
+    payload = torch.zeros(max(max(counts), 1) * item, dtype=torch.uint8, device=device)
     if local.size:
         payload[: local.nbytes] = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(device)
     bucket = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
@@ -93,9 +88,21 @@ def gather_ibd_records(rec: np.ndarray, pair_offset: int, dist, rank: int, world
     if rank != 0:
         return sum(counts), None
     parts = [bucket[r][: counts[r] * item].cpu().numpy().view(local.dtype) for r in range(world)]
-    out = np.concatenate(parts) if parts else local[:0]
-    # shards are contiguous and each is already ordered, so concatenation is the single-device order
-    return sum(counts), out
+    return sum(counts), np.concatenate(parts)
+
+
+def gather_ibd_records(rec: np.ndarray, pair_offset: int, dist, rank: int, world: int, device="cpu",
+                       force_collective: bool = False):
+    """Gather every rank's IBD records (structured array with a ``pair`` field holding *local* pair indices) to
+    rank 0: all_gather of counts, then gather of padded byte payloads.  Returns (total_count, records_or_None);
+    on rank 0 the records carry global pair indices and are ordered like a single-device run (shards are contiguous
+    and each is already ordered, so the concatenation in rank order IS that order).  A group of one rank returns its
+    own records without a collective unless ``force_collective`` (the one-rank rehearsal of the RCCL leg)."""
+    local = rec.copy()
+    local["pair"] += np.uint32(pair_offset)
+    if dist is None or (world == 1 and not force_collective):
+        return int(local.size), local
+    return _gather_records(local, dist, rank, world, device)
 
 
 def run_fastsmc_sharded(params, rank: int | None = None, world: int | None = None, local_rank: int | None = None,
@@ -148,33 +155,19 @@ IBD_COLUMNS = (("pair", np.uint64), ("hap_a", np.uint32), ("hap_b", np.uint32), 
 IBD_ROW_DTYPE = np.dtype([(n, np.dtype(t).newbyteorder("<")) for n, t in IBD_COLUMNS])
 
 
-def gather_hmm_records(hmm, dist=None, rank: int = 0, world: int = 1, device="cpu"):
+def gather_hmm_records(hmm, dist=None, rank: int = 0, world: int = 1, device="cpu", force_collective: bool = False):
     """The in-memory counterpart of ``run_fastsmc_sharded``'s part files: every rank's kept IBD records
     (``HMM.setKeepIbdRecords(True)``; ``HMM.getIbdRecordArrays()``) gathered to rank 0 over the process group -- RCCL over
     xGMI with backend "nccl" and ``device="cuda"``, gloo in CPU tests -- as one structured array (``IBD_ROW_DTYPE``).
     Shards are contiguous ranges of the job's batches and each rank's records are in output order, so the
     concatenation in rank order IS the single-GPU record stream (``pair`` = the record's pair ordinal within its rank's
     shard).  Returns (total_count, records on rank 0 / None elsewhere).  The only collective of the path: an all_gather
-    of the counts and one gather of padded payloads."""
+    of the counts and one gather of padded payloads (``_gather_records``); a group of one rank skips it unless
+    ``force_collective``."""
     cols = hmm.getIbdRecordArrays()
     local = np.zeros(cols["pair"].size, IBD_ROW_DTYPE)
     for name, _ in IBD_COLUMNS:
         local[name] = cols[name]
-    if dist is None or world == 1:
+    if dist is None or (world == 1 and not force_collective):
         return int(local.size), local
-    import torch
-
-    cnt = torch.tensor([local.size], device=device, dtype=torch.int64)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt)
-    counts = [int(c.item()) for c in counts]
-    item = IBD_ROW_DTYPE.itemsize
-    payload = torch.zeros(max(max(counts), 1) * item, dtype=torch.uint8, device=device)
-    if local.size:
-        payload[: local.nbytes] = torch.from_numpy(local.view(np.uint8).reshape(-1).copy()).to(device)
-    bucket = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
-    dist.gather(payload, bucket, dst=0)
-    if rank != 0:
-        return sum(counts), None
-    parts = [bucket[r][: counts[r] * item].cpu().numpy().view(IBD_ROW_DTYPE) for r in range(world)]
-    return sum(counts), np.concatenate(parts)
+    return _gather_records(local, dist, rank, world, device)

@@ -12,8 +12,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
-def small_problem():
+def build_small_problem():
     """A seeded synthetic problem small enough for the CPU oracle: 64 haplotypes x 640 sites, K = 69."""
     import numpy as np
     from fastsmc_amd import synth
@@ -26,6 +25,11 @@ def small_problem():
     gen = (haps.cm / 100.0).astype(np.float32)
     model = O.prepare_model(tables, gen, haps.bp, derived, 64, time=50)
     return dict(tables=tables, haps=haps, bits=bits, folded=folded, gen=gen, model=model)
+
+
+@pytest.fixture(scope="session")
+def small_problem():
+    return build_small_problem()
 
 
 @pytest.fixture(scope="session")

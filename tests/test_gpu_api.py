@@ -13,10 +13,16 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def files(small_problem, tmp_path_factory):
-    sp = small_problem
-    root = str(tmp_path_factory.mktemp("data") / "syn")
+def make_files(dirpath, sp=None):
+    """The small problem as the reference's input files (.hap.gz / .samples / .map / .decodingQuantities.gz) under
+    `dirpath`; returns the file root.  (Also called from child processes of other tests.)"""
+    import os
+
+    if sp is None:
+        from conftest import build_small_problem
+
+        sp = build_small_problem()
+    root = os.path.join(str(dirpath), "syn")
     synth.write_haps_files(root, sp["haps"])
     used = np.unique(np.concatenate([[0.0], O.step_rows(sp["tables"].keys, sp["gen"])[1][1:]]))
     t = copy.copy(sp["tables"])
@@ -24,6 +30,11 @@ def files(small_problem, tmp_path_factory):
     t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
     synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
     return root
+
+
+@pytest.fixture(scope="module")
+def files(small_problem, tmp_path_factory):
+    return make_files(tmp_path_factory.mktemp("data"), small_problem)
 
 
 def _params(root, out, **kw):
