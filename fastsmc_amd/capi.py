@@ -26,6 +26,7 @@ FSMC_EOVERFLOW = -6
 # every symbol include/fastsmc_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
+    "fsmc_ctx_expect_work",
     "fsmc_ctx_set_chunk_sites", "fsmc_ctx_set_beta_stride", "fsmc_ctx_last_beta_stride", "fsmc_ctx_last_plan",
     "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items", "fsmc_ctx_set_resident_chunks",
     "fsmc_ctx_last_resident_chunks",
@@ -94,6 +95,7 @@ def load():
         L.fsmc_last_error.restype = C.c_char_p
         L.fsmc_ctx_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]
         L.fsmc_ctx_set_workspace_limit.argtypes = [vp, u64]
+        L.fsmc_ctx_expect_work.argtypes = [vp, C.c_double, C.c_int32]
         L.fsmc_ctx_set_chunk_sites.argtypes = [vp, u32]
         L.fsmc_ctx_set_beta_stride.argtypes = [vp, u32]
         L.fsmc_ctx_last_beta_stride.argtypes = [vp, C.POINTER(i32)]
@@ -220,6 +222,10 @@ class Context:
 
     def set_workspace_limit(self, nbytes: int):
         self._check(self._L.fsmc_ctx_set_workspace_limit(self._h, nbytes))
+
+    def expect_work(self, pair_sites: float, states: int):
+        """Announce the job (pair-sites the coming launches decode): its workspace credit is there at the first launch."""
+        self._check(self._L.fsmc_ctx_expect_work(self._h, float(pair_sites), int(states)))
 
     def create_model(self, pm) -> "Model":
         """pm: any object with the PreparedModel fields (K, S, pi, col_ratios, exp_times, D, B, U, RR,

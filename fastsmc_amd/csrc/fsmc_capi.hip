@@ -65,7 +65,9 @@ struct fsmc_ctx {
   int nCU = 0;
   uint64_t hbmBytes = 0;
   uint64_t wsLimit = 0;
-  double wsEarned = 0; // bytes of workspace the launches so far have paid for (earnWorkspace)
+  double wsEarned = 0; // bytes of workspace the launches so far (and the announced job) have paid for and not yet
+                       // spent on an allocation (earnWorkspace, fsmc_ctx_expect_work, planLaunch)
+  double wsAnnounced = 0; // estimated kernel seconds of announced work not launched yet (it has earned already)
   std::string err;
 
   unsigned long long* dHaps = nullptr;
@@ -417,7 +419,13 @@ struct LaunchPlan {
 // earned: hipMalloc costs ~40 ms per GB on this driver (230 GB: 4.4-9 s; tools/malloc_cost.py), a rebuilt chunk costs a
 // few per cent of a launch, so a run of a few seconds must not start by allocating the card.  Every launch adds what
 // it is expected to save -- kEarnFraction of its estimated kernel time -- at the allocation rate; the buffer is kept
-// between launches, so a long job reaches the full card within its first minutes and a short one stays small.
+// between launches, so a long job reaches the full card and a short one stays small.
+// A bigger buffer is a NEW allocation of its whole size (free + hipMalloc), so growth is amortised and every byte is
+// paid for once: an upgrade is considered only when the credit covers twice the buffer held (or the whole hard
+// budget), and an allocation is debited from the credit.  Creeping up a resident chunk per flush -- 16 allocations of
+// 27 ... 230 GB, 80 s of hipMalloc on a 390-s job -- is what this replaces.  A caller that knows its job announces it
+// (fsmc_ctx_expect_work: HMM::decodeAll knows its pair count, HMM.cpp:310-321): the credit of the whole job is there
+// at the first launch, and a job long enough to pay for the card allocates it once, at the start.
 // `cur`: the buffer about to be re-used (what it holds is paid for).
 constexpr double kAllocBytesPerSecond = 25e9; // measured: hipMalloc of 64 / 128 GB takes 2.4 / 5.2 s
 constexpr double kEarnFraction = 0.06;        // what resident chunks save of a chunked launch (C2: 1974 -> 1854 ms)
@@ -426,6 +434,14 @@ constexpr uint64_t kFreeWorkspace = 24ull << 30; // never argued about (at most 
 struct WsBudget {
   uint64_t hard, soft;
 };
+
+uint64_t freeWorkspace()
+{
+  if (const char* v = std::getenv("FSMC_DIAG_WS_FREE")) { // tests: make the policy visible on a small problem
+    return std::strtoull(v, nullptr, 10);
+  }
+  return kFreeWorkspace;
+}
 
 WsBudget workspaceBudget(const fsmc_ctx* ctx, const DevBuf& cur)
 {
@@ -448,13 +464,33 @@ WsBudget workspaceBudget(const fsmc_ctx* ctx, const DevBuf& cur)
     const uint64_t want = (uint64_t)(0.80 * (double)ctx->hbmBytes);
     hard = std::max<uint64_t>(floor40, std::min<uint64_t>(want, reachable > margin ? reachable - margin : 0));
   }
-  const uint64_t earned = (uint64_t)std::min(ctx->wsEarned, 1e15);
-  uint64_t freeBytes = kFreeWorkspace;
-  if (const char* v = std::getenv("FSMC_DIAG_WS_FREE")) { // tests: make the policy visible on a small problem
-    freeBytes = std::strtoull(v, nullptr, 10);
+  uint64_t earned = (uint64_t)std::min(std::max(ctx->wsEarned, 0.0), 1e15);
+  if (earned < hard && earned < 2 * (uint64_t)cur.bytes) {
+    earned = 0; // (not yet worth a re-allocation: growth is geometric)
   }
+  const uint64_t freeBytes = freeWorkspace();
   const uint64_t soft = std::min<uint64_t>(hard, std::max<uint64_t>({(uint64_t)cur.bytes, earned, freeBytes}));
   return {hard, soft};
+}
+
+// An allocation of the workspace under the earned policy is debited from the credit (beyond the free allowance).
+void payForWorkspace(fsmc_ctx* ctx, uint64_t allocatedBytes)
+{
+  if (ctx->wsLimit) {
+    return;
+  }
+  const uint64_t freeBytes = freeWorkspace();
+  if (allocatedBytes > freeBytes) {
+    ctx->wsEarned = std::max(0.0, ctx->wsEarned - (double)(allocatedBytes - freeBytes));
+  }
+}
+
+double earnScale()
+{
+  if (const char* v = std::getenv("FSMC_DIAG_WS_EARN_SCALE")) { // tests: a small problem that earns like a long job
+    return std::atof(v);
+  }
+  return 1.0;
 }
 
 // A launch over the uploaded work list earns workspace for this and the following launches: estimated kernel time =
@@ -466,12 +502,12 @@ void earnWorkspace(fsmc_ctx* ctx, const fsmc_model* m, int mode)
     const uint32_t aEnd = (mode == kModeIbd) ? g.scan_to : g.to;
     pairSites += (double)g.n_pairs * (double)(aEnd > g.from ? aEnd - g.from : 0);
   }
-  const double seconds = pairSites * (8.0 * m->K + 0.25) / (0.8 * 8e12);
-  double scale = 1.0;
-  if (const char* v = std::getenv("FSMC_DIAG_WS_EARN_SCALE")) { // tests: a small problem that earns like a long job
-    scale = std::atof(v);
-  }
-  ctx->wsEarned += scale * kEarnFraction * seconds * kAllocBytesPerSecond;
+  double seconds = pairSites * (8.0 * m->K + 0.25) / (0.8 * 8e12);
+  // (work that was announced has earned already: fsmc_ctx_expect_work)
+  const double announced = std::min(ctx->wsAnnounced, seconds);
+  ctx->wsAnnounced -= announced;
+  seconds -= announced;
+  ctx->wsEarned += earnScale() * kEarnFraction * seconds * kAllocBytesPerSecond;
 }
 
 int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, LaunchPlan& plan,
@@ -528,9 +564,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   const size_t sideRows = anyStates(m) ? (size_t)kAnyExtraRows + 2 : 4;
   const size_t defaultChunk = std::max<size_t>((size_t)std::ceil(std::sqrt((double)L)), w2 ? 2048 : 512);
   size_t C, maxChunks;
-  // A window stays whole if that fits what the launches have earned (or is no longer than a chunk would be anyway; a
-  // paired launch only has this layout and was planned within the same budget).
-  // (an explicit chunk length is kept, except for paired launches)
+  // A window stays whole if that fits what the launches have earned (or is no longer than a chunk would be anyway).
+  // An explicit chunk length (fsmc_ctx_set_chunk_sites) is kept -- by the paired kernel too, which has the chunked
+  // layout since round 3.
   if (chunkRows(L) + sideRows + 1 <= rowsAvail && (chunkRows(L) + sideRows + 1 <= rowsSoft || L <= defaultChunk) &&
       !(ctx->chunkSites && ctx->chunkSites < L)) {
     C = L;
@@ -557,7 +593,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   // Resident chunks (fsmc_kernels.h): a chunked window rebuilds every chunk's rows from a checkpoint -- one of its 3.5
   // sweeps -- except for the chunks whose rows pass B can leave in the workspace.  Whatever the limit leaves after the
   // one chunk buffer, the checkpoints and the parking rows goes to such chunks (array-mode IBD decode of the
-  // lane-per-pair family; paired launches are single-chunk).
+  // lane-per-pair family, one group per wave: the paired kernel is not built with them).
   size_t resident = 0;
   if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && !anyStates(m) && ctx->residentChunks != 0) {
     const size_t rowsBudget = rowsSoft;
@@ -578,7 +614,13 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   ctx->lastChunk = plan.chunk;
   ctx->lastMaxChunks = plan.maxChunks;
   ctx->lastResident = plan.residentChunks;
-  return ensure(ctx, ws ? *ws : ctx->ws, plan.wsSlot * sizeof(float4) * slots);
+  DevBuf& buf = ws ? *ws : ctx->ws;
+  const size_t held = buf.bytes;
+  const int rc = ensure(ctx, buf, plan.wsSlot * sizeof(float4) * slots);
+  if (rc == FSMC_OK && buf.bytes != held) {
+    payForWorkspace(ctx, buf.bytes);
+  }
+  return rc;
 }
 
 int checkReady(fsmc_ctx* ctx, const fsmc_model* m)
@@ -838,6 +880,22 @@ int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes)
     return FSMC_EINVAL;
   }
   ctx->wsLimit = bytes;
+  return FSMC_OK;
+}
+
+int fsmc_ctx_expect_work(fsmc_ctx* ctx, double pair_sites, int32_t states)
+{
+  if (!ctx) {
+    return fail(nullptr, FSMC_EINVAL, "null context");
+  }
+  if (!(pair_sites >= 0) || states < 1) {
+    return fail(ctx, FSMC_EINVAL, "expected work: pair-sites >= 0 and states >= 1");
+  }
+  // the job's launches will save what workspace upgrades save of its estimated kernel time: its credit is there at the
+  // first launch (workspaceBudget); the launches themselves then earn nothing until the announced work is used up
+  const double seconds = pair_sites * (8.0 * states + 0.25) / (0.8 * 8e12);
+  ctx->wsAnnounced += seconds;
+  ctx->wsEarned += earnScale() * kEarnFraction * seconds * kAllocBytesPerSecond;
   return FSMC_OK;
 }
 
@@ -1144,8 +1202,9 @@ namespace
 bool buildDualItems(const std::vector<fsmc_group>& groups, uint32_t maxLen, std::vector<fsmc_group>& items,
                     std::vector<fsmc_group>& unions, std::vector<fsmc_group>& rest)
 {
-  // half-full groups whose window (and so the union with a neighbour of the same length class) fits the single-chunk
-  // layout are candidates; everything else -- full groups, long windows -- runs as uploaded, in a second kernel
+  // half-full groups whose window (and so the union with a neighbour of the same length class) is within `maxLen`
+  // are candidates (the paired kernel decodes in chunks too, so the callers pass no real bound any more); everything
+  // else -- full groups -- runs as uploaded, in a second kernel
   std::vector<uint32_t> small;
   for (size_t g = 0; g < groups.size(); ++g) {
     if (groups[g].n_pairs <= 32 && (uint64_t)(groups[g].to - groups[g].from) * 5 <= (uint64_t)maxLen * 4) {
@@ -1270,7 +1329,7 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   const bool track = (flags & (FSMC_WANT_MEAN | FSMC_WANT_MAP)) != 0;
   earnWorkspace(ctx, m, kModeIbd);
-  // The queues.  Two half-groups per wave for the half-full groups that pair up within the single-chunk layout
+  // The queues.  Two half-groups per wave for the half-full groups that pair up
   // (decode_kernel<..., DUAL>, with beta stride 2 where that is built); the other groups one per wave, in a kernel that
   // runs beside it.
   KernelFn fnDual = nullptr;
@@ -1328,7 +1387,6 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
     if (rc != FSMC_OK) {
       return rc;
     }
-
   }
   KernelFn fn = pickKernel(kModeIbd, track, m, false); // (after the paired pick: last_kernel / last_beta_stride name this one)
   if (haveRest) {
@@ -1535,6 +1593,11 @@ int fsmc_identify_ex(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint
         }
       }
       (void)hipFree(full);
+    }
+    if (ctx->idStashCount == 0) {
+      // the second run did not go through (e.g. no memory for the full list): nothing is kept, the caller calls again
+      // with a buffer of *n_out records -- and must not find this failure's error state in front of that call's checks
+      (void)hipGetLastError();
     }
     return fail(ctx, FSMC_EOVERFLOW, "fsmc_identify: candidate buffer too small");
   }

@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   // p.residentChunks extra chunk buffers per wave) pass B keeps them and pass A sweeps those chunks without rebuilding
   // them: the same rows, bit for bit (the rebuild repeats pass B's operations on the same operands).
   float4* const resBase = saveS + vecF4;
-  // (array-mode IBD decode, one group per wave: paired launches are single-chunk by construction)
+  // (array-mode IBD decode, one group per wave: the paired kernel is chunked too, but keeps no resident chunks)
   constexpr bool kResidentBuilt = !SEQ && !DUAL && MODE == kModeIbd;
   const int nResident = kResidentBuilt ? p.residentChunks : 0;
   const int C = p.chunk;

@@ -298,6 +298,15 @@ void runHashing(const Data& data, const DecodingParams& params, HMM& hmm)
     first = std::min(all.size(), bLo * B);
     last = std::min(all.size(), std::max(bLo, bHi) * B);
   }
+  // the candidates' windows, padded like a batch's (roughly: every batch decodes the union of its members' windows):
+  // the size of the job, announced before its first flush (fsmc_ctx_expect_work)
+  double pairSites = 0;
+  for (size_t i = first; i < last; ++i) {
+    pairSites += static_cast<double>(all[i].to - all[i].from + 1);
+  }
+  if (pairSites > 0) {
+    hmm.announceWork(pairSites);
+  }
   for (size_t i = first; i < last; ++i) {
     hmm.decodeFromHashing(all[i].hapA, all[i].hapB, all[i].from, all[i].to);
   }

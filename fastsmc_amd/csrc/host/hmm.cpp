@@ -804,8 +804,26 @@ void HMM::decodeAll(int jobs, int jobInd)
       return; // pairs arrive through decodeFromHashing
     }
   }
+  // the job's size is known here (its pair range, HMM.cpp:310-321): announce it, so that a long job under the
+  // library's own workspace policy allocates once at its start instead of growing into the card (fsmc_ctx_expect_work)
+  unsigned long long nPairsOfJob = 0;
+  forEachPairOfJob(jobs, jobInd, true, [&](unsigned, unsigned) { nPairsOfJob++; });
+  if (nPairsOfJob) {
+    announceWork(static_cast<double>(nPairsOfJob) * static_cast<double>(mData.sites));
+  }
   forEachPairOfJob(jobs, jobInd, true, [&](unsigned a, unsigned b) { queuePair(a, b); });
   finishDecoding();
+}
+
+void HMM::announceWork(double pairSites)
+{
+  // every consumer of a flush is a launch over the same pairs (IBD decode; sums over pairs)
+  int launches = 0;
+  if (mParams.FastSMC) launches++;
+  if (mParams.doPosteriorSums || mParams.doMajorMinorPosteriorSums) launches++;
+  if (launches == 0) launches = 1;
+  check(engine(), fsmc_ctx_expect_work(engine(), pairSites * launches, static_cast<int32_t>(mDq.states)),
+        "fsmc_ctx_expect_work");
 }
 
 void HMM::decodePairs(const std::vector<unsigned>& A, const std::vector<unsigned>& B)

@@ -143,6 +143,8 @@ public:
   int batchSize() const { return mBatchSize; }
   // the device context of this HMM (opened on first use; the identification step runs on it before any decode)
   fsmc_ctx* engine();
+  // tell the engine how many pair-sites the coming flushes will decode (fsmc_ctx_expect_work: workspace policy)
+  void announceWork(double pairSites);
 
   // keep emitted IBD records in memory as well (tests, benchmarks)
   void setKeepIbdRecords(bool v) { mKeepRecords = v; }

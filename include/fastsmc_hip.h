@@ -126,9 +126,17 @@ int fsmc_ctx_info(const fsmc_ctx* ctx, int32_t* n_cu, int32_t* n_slots, uint64_t
  * 0 (default): the library's own policy.  The rows a decode cannot do without may take up to 80 % of the card (at least
  * 40 %); everything beyond them is EARNED: hipMalloc costs about 40 ms per GB on this driver, so a context starts with a
  * free allowance of 24 GB and every launch adds what an upgraded plan is expected to save of it (6 % of its estimated
- * kernel time, at the allocation rate) -- a job of minutes has the whole card after its first minutes, a run of seconds
- * does not spend them allocating.  The buffer is kept for the life of the context. */
+ * kernel time, at the allocation rate) -- a run of seconds does not spend them allocating.  Growth is
+ * amortised and every byte is paid for once: a bigger buffer is a new allocation of its whole size, so the plan is
+ * upgraded only when the credit covers twice the buffer held (or the whole budget), and an allocation is debited from
+ * the credit.  The buffer is kept for the life of the context. */
 int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes);
+/* The caller announces the work the context's coming launches will decode -- pair-sites (pairs x sites of their decode
+ * windows) of a model of `states` states: what the reference's HMM::decodeAll knows when it starts (its job's pair
+ * range, HMM.cpp:310-321).  Under the library's own workspace policy (no limit set) the credit of the whole job is
+ * then there at the first launch: a job long enough to pay for the card allocates it once, at its start, instead of
+ * growing into it; a short job stays small.  The announced launches earn nothing again.  No effect with a limit set. */
+int fsmc_ctx_expect_work(fsmc_ctx* ctx, double pair_sites, int32_t states);
 /* Tuning: sites between beta checkpoints when a decode window does not fit the workspace (0 = automatic:
  * max(512, ceil(sqrt(window))), 2048 for the wave-group kernel, rounded up to 16).  Results do not depend on it. */
 int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites);
