@@ -10,11 +10,11 @@ import numpy as np
 from . import _pyasmc
 from ._pyasmc import (ASMC, BinaryDataReader, Data, DecodePairsReturnStruct, DecodingMode, DecodingModeOverall,  # noqa: F401
                       DecodingParams, DecodingQuantities, DecodingReturnValues, FastSMC, HMM, IbdPairDataLine, Individual,
-                      Match, PairObservations, cmBetween, hashingCandidates, hashingCandidatesDevice)
+                      Match, PairObservations, cmBetween, hashingCandidates, hashingCandidatesDevice, hashingWords)
 
 __all__ = ["ASMC", "BinaryDataReader", "IbdPairDataLine", "Data", "DecodePairsReturnStruct", "DecodingMode", "DecodingModeOverall", "DecodingParams",
            "DecodingQuantities", "DecodingReturnValues", "FastSMC", "HMM", "Individual", "PairObservations", "Match", "cmBetween",
-           "hashingCandidates", "hashingCandidatesDevice",
+           "hashingCandidates", "hashingCandidatesDevice", "hashingWords",
            "decoding_quantities_from_tables", "PreparedModelView"]
 
 

@@ -61,6 +61,10 @@ public:
   // the GPU step in tests/ -- no product path calls it.
   template <typename Sink> void run(Sink&& sink);
   unsigned long numWords() const { return mNumWords; }
+  // the words the identification step compares, [haplotype row][word]: bit b of word w = the allele of the b-th site
+  // of the word -- Individuals::setMarker(w, snp_ctr) / getWordHash (Individuals.hpp:46-59, FastSMC.cpp:176-186)
+  const std::vector<uint64_t>& words() const { return mWords; }
+  size_t numHaps() const { return mNumHaps; }
 
 private:
   bool pairInJob(unsigned hapI, unsigned hapJ) const; // SeedHash.hpp:93-128 (hapJ < hapI, local rows)

@@ -15,6 +15,8 @@
 #include <sstream>
 #include <stdexcept>
 
+#include <sys/stat.h>
+
 #include "util.hpp"
 
 namespace fsmc_host
@@ -229,6 +231,7 @@ void HMM::init(int scalingSkip)
 
 HMM::~HMM()
 {
+  closePerPairFiles();
   if (mIbdFile) {
     gzclose(mIbdFile);
   }
@@ -418,11 +421,82 @@ void HMM::prepareModel()
   }
   mPrep.probabilityThreshold = pthr;
   mPrep.ageThreshold = mParams.noConditionalAgeEstimates ? mDq.states : st;
+  // expected coalescence times of the per-pair posterior means (HMM.cpp:1736-1748): the second column of the intervals
+  // file when one is given (ASMC mode), else the decoding quantities' own
   mExpectedCoalTimes = mDq.expectedTimes;
+  if (!mParams.FastSMC && !mParams.expectedCoalTimesFile.empty() && isRegularFile(mParams.expectedCoalTimesFile)) {
+    mExpectedCoalTimes = readExpectedTimesFromIntervalsFile(mParams.expectedCoalTimesFile);
+    if (mExpectedCoalTimes.size() != mDq.states) {
+      throw std::runtime_error(mParams.expectedCoalTimesFile + " has " + std::to_string(mExpectedCoalTimes.size()) +
+                               " intervals, the decoding quantities have " + std::to_string(mDq.states) + " states");
+    }
+  }
+}
+
+// HMM.cpp:43-61: "intervalStart expectedCoalescentTime intervalEnd" on every line; the second column
+std::vector<float> readExpectedTimesFromIntervalsFile(const std::string& fileName)
+{
+  LineReader in(fileName);
+  std::vector<float> out;
+  std::string line;
+  while (in.getline(line)) {
+    const std::vector<std::string> tok = splitWhitespace(line);
+    if (tok.size() != 3) {
+      throw std::runtime_error(fileName + " should have \"intervalStart\texpectedCoalescentTime\tintervalEnd\" at each line.");
+    }
+    out.push_back(refStof(tok[1]));
+  }
+  return out;
+}
+
+bool isRegularFile(const std::string& path)
+{
+  struct stat st{};
+  return ::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+void HMM::closePerPairFiles()
+{
+  if (mMeanFile) {
+    gzclose(mMeanFile);
+    mMeanFile = nullptr;
+  }
+  if (mMapFile) {
+    gzclose(mMapFile);
+    mMapFile = nullptr;
+  }
+}
+
+void HMM::setWritePerPairPosteriorMean(bool v)
+{
+  mWriteMean = v;
+  resetDecoding(); // (updateOutputStructures ends in resetDecoding, HMM.cpp:1757)
+}
+
+void HMM::setWritePerPairMap(bool v)
+{
+  mWriteMap = v;
+  resetDecoding();
 }
 
 void HMM::resetDecoding()
 {
+  // HMM.cpp:259-271: the per-pair text outputs of ASMC mode are (re)opened here
+  closePerPairFiles();
+  auto openOut = [&](const std::string& suffix) {
+    const std::string name = mParams.outFileRoot + suffix;
+    gzFile f = gzopen(name.c_str(), "w");
+    if (!f) {
+      throw std::runtime_error("ERROR: could not open " + name);
+    }
+    return f;
+  };
+  if (mWriteMean && !mParams.FastSMC) {
+    mMeanFile = openOut(".perPairPosteriorMeans.gz");
+  }
+  if (mWriteMap && !mParams.FastSMC) {
+    mMapFile = openOut(".perPairMAP.gz");
+  }
   const size_t n = static_cast<size_t>(mData.sites) * mDq.states;
   mReturn.sumOverPairs.assign(n, 0.f);
   if (mParams.doMajorMinorPosteriorSums) {
@@ -646,18 +720,20 @@ void HMM::flush()
                                    mm ? mReturn.sumOverPairs11.data() : nullptr),
           "fsmc_decode_sums_batches");
   }
-  if (!mParams.FastSMC && (mStoreMean || mStoreMap || mStorePosterior || mStoreSumOfPosterior)) {
+  const bool writeFiles = mMeanFile || mMapFile;
+  const bool storeAny = mStoreMean || mStoreMap || mStorePosterior || mStoreSumOfPosterior;
+  if (!mParams.FastSMC && (storeAny || writeFiles)) {
     // writePerPairOutput (HMM.cpp:1360-1458)
     const size_t S = static_cast<size_t>(mData.sites);
     const size_t K = mDq.states;
     auto& R = mPairsReturn;
     const size_t base = R.numWritten;
-    if (base + nPairs > static_cast<size_t>(R.numPairs)) {
+    if (storeAny && base + nPairs > static_cast<size_t>(R.numPairs)) {
       throw std::runtime_error("more pairs decoded than the return structure was initialised for");
     }
-    const bool wantMean = mStoreMean || mStorePosterior || mStoreSumOfPosterior;
+    const bool wantMean = mStoreMean || mStorePosterior || mStoreSumOfPosterior || mMeanFile;
     std::vector<float> mean(wantMean ? nPairs * S : 0);
-    std::vector<int32_t> map(mStoreMap || mStoreMean ? nPairs * S : 0);
+    std::vector<int32_t> map(mStoreMap || mStoreMean || mMapFile ? nPairs * S : 0);
     check(mCtx,
           fsmc_decode_per_pair(mCtx, mModel, mExpectedCoalTimes.data(), mean.empty() ? nullptr : mean.data(),
                                map.empty() ? nullptr : map.data()),
@@ -684,7 +760,44 @@ void HMM::flush()
         }
       }
     }
-    for (size_t i = 0; i < nPairs; ++i) {
+    if (writeFiles) {
+      // HMM.cpp:1412-1420: `fout << matrix.topRows(actualBatchSize).format(m_eigenOutputFormat)` once per BATCH, with
+      // IOFormat(FullPrecision, DontAlignCols, " ", "\n") (HMM.hpp:154): coefficients separated by a blank, rows by a
+      // newline -- a separator BETWEEN rows: nothing follows a batch's last row, so the next batch's first row
+      // continues that line.  Reproduced as it is (the files are the reference's, quirk included): a newline goes in
+      // front of every row that is not the first of its batch.  FullPrecision for float is the stream at
+      // NumTraits<float>::digits10() = 6 significant digits (Eigen 3.4, the version the reference's unpinned vcpkg
+      // dependency resolves to; general notation = "%.6g"); the MAP matrix is integer.
+      const auto B = static_cast<uint64_t>(mBatchSize);
+      std::string text;
+      char buf[48];
+      auto writeRows = [&](gzFile f, auto&& cell) {
+        text.clear();
+        for (size_t i = 0; i < nPairs; ++i) {
+          if ((mPairsFlushed + i) % B != 0) {
+            text.push_back('\n');
+          }
+          for (size_t pos = 0; pos < S; ++pos) {
+            if (pos) {
+              text.push_back(' ');
+            }
+            text.append(buf, static_cast<size_t>(cell(buf, sizeof(buf), i * S + pos)));
+          }
+          if (text.size() > (1u << 22)) {
+            gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
+            text.clear();
+          }
+        }
+        gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
+      };
+      if (mMeanFile) {
+        writeRows(mMeanFile, [&](char* b, size_t n, size_t idx) { return std::snprintf(b, n, "%.6g", static_cast<double>(mean[idx])); });
+      }
+      if (mMapFile) {
+        writeRows(mMapFile, [&](char* b, size_t n, size_t idx) { return std::snprintf(b, n, "%d", map[idx]); });
+      }
+    }
+    for (size_t i = 0; storeAny && i < nPairs; ++i) {
       const auto [indA, hapA] = hapToDipId(mPairs[i].hap_a);
       const auto [indB, hapB] = hapToDipId(mPairs[i].hap_b);
       R.perPairIndices.at(base + i) =
@@ -698,7 +811,9 @@ void HMM::flush()
         }
       }
     }
-    R.numWritten += nPairs;
+    if (storeAny) {
+      R.numWritten += nPairs;
+    }
   }
 
   // keep any pairs of a still-open batch
@@ -884,6 +999,7 @@ void HMM::finishDecoding()
 {
   closeBatch(true);
   flush();
+  closePerPairFiles(); // HMM.cpp:518-523
   if (!(mParams.FastSMC && mParams.hashing)) {
     std::fill(mFromBatch.begin(), mFromBatch.end(), 0u);
     std::fill(mToBatch.begin(), mToBatch.end(), static_cast<unsigned>(mData.sites));

@@ -128,6 +128,12 @@ public:
   void setStorePerPairMap(bool v) { mStoreMap = v; }
   void setStorePerPairPosterior(bool v) { mStorePosterior = v; }
   void setStoreSumOfPosterior(bool v) { mStoreSumOfPosterior = v; }
+  // HMM.hpp:287,293: per-pair posterior means / MAP states of every decoded pair as text, one row per pair, to
+  // <outFileRoot>.perPairPosteriorMeans.gz / .perPairMAP.gz (ASMC mode; opened by resetDecoding, HMM.cpp:259-271,
+  // written batch by batch, HMM.cpp:1412-1420, closed by finishDecoding, HMM.cpp:515-524)
+  const std::vector<float>& getExpectedCoalTimes() const { return mExpectedCoalTimes; }
+  void setWritePerPairPosteriorMean(bool v = true);
+  void setWritePerPairMap(bool v = true);
   void resetDecoding(); // HMM.cpp:258-280
 
   // Multi-GPU: this process decodes shard `rank` of `world` -- a contiguous range of the job's batches (whole
@@ -200,6 +206,9 @@ private:
   DecodingReturnValues mReturn;
   DecodePairsReturnStruct mPairsReturn;
   bool mStoreMean = false, mStoreMap = false, mStorePosterior = false, mStoreSumOfPosterior = false;
+  bool mWriteMean = false, mWriteMap = false;
+  gzFile mMeanFile = nullptr, mMapFile = nullptr;
+  void closePerPairFiles();
   bool mKeepRecords = false;
   std::vector<fsmc_ibd_record> mKeptRecords;
   std::vector<fsmc_pair> mKeptPairs;
@@ -207,6 +216,10 @@ private:
   uint64_t mPairsFlushed = 0; // pairs of the flushes before the current one
   std::vector<float> mExpectedCoalTimes;
 };
+
+// HMM.cpp:43-61: second column of an intervals file ("intervalStart expectedCoalescentTime intervalEnd" per line)
+std::vector<float> readExpectedTimesFromIntervalsFile(const std::string& fileName);
+bool isRegularFile(const std::string& path);
 
 // helpers shared with the drivers (HmmUtils.cpp)
 float roundMorgans(float value, int precision, float min);                      // HmmUtils.cpp:65-79

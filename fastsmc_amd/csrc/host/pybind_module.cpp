@@ -374,6 +374,15 @@ PYBIND11_MODULE(_pyasmc, m)
            "PairObservations of the open batch; empty whenever a batch has just filled up (HMM.hpp:215)")
       .def("getQueuedPairs", &HMM::getQueuedPairs, "pairs waiting for the next launch, full batches included")
       .def("finishDecoding", &HMM::finishDecoding)
+      .def("setWritePerPairPosteriorMean", &HMM::setWritePerPairPosteriorMean, "writePerPairPosteriorMean"_a = true,
+           "ASMC mode: write <outFileRoot>.perPairPosteriorMeans.gz, one row per decoded pair (HMM.hpp:287, HMM.cpp:1412-1416)")
+      .def("setWritePerPairMap", &HMM::setWritePerPairMap, "writePerPairMAP"_a = true,
+           "ASMC mode: write <outFileRoot>.perPairMAP.gz, one row per decoded pair (HMM.hpp:293, HMM.cpp:1417-1420)")
+      .def("setStorePerPairPosteriorMean", &HMM::setStorePerPairPosteriorMean, "storePerPairPosteriorMean"_a = true)
+      .def("setStorePerPairMap", &HMM::setStorePerPairMap, "storePerPairMAP"_a = true)
+      .def("getExpectedCoalTimes", &HMM::getExpectedCoalTimes,
+           "expected coalescence times the per-pair posterior means use: the intervals file's second column when "
+           "DecodingParams.expectedCoalTimesFile names one, else the decoding quantities' (HMM.cpp:1736-1748)")
       .def("finishFromHashing", &HMM::finishFromHashing)
       .def("closeIBDFile", &HMM::closeIBDFile)
       .def("getDecodingQuantities", &HMM::getDecodingQuantities, py::return_value_policy::reference_internal)
@@ -512,6 +521,15 @@ PYBIND11_MODULE(_pyasmc, m)
         "data"_a, "params"_a,
         "candidate (hapA, hapB, fromSite, toSite) list of the identification step from the HOST restatement of the "
         "reference's hash maps -- the checker of hashingCandidatesDevice in the tests; FastSMC.run() does not use it");
+  m.def("hashingWords",
+        [](const Data& d, const DecodingParams& p) {
+          const HashingPrefilter pf(d, p);
+          return toArray<uint64_t>(pf.words(), {static_cast<py::ssize_t>(pf.numHaps()),
+                                                static_cast<py::ssize_t>(pf.numWords())});
+        },
+        "data"_a, "params"_a,
+        "the hashing words of every haplotype row, [haps][words] uint64: what Individuals::getWordHash returns for "
+        "word w of the haplotype (Individuals.hpp:46-59) -- hashingWordSize sites to a word, MAF-filtered sites skipped");
   m.def("hashingCandidatesDevice",
         [](const Data& d, const DecodingParams& p, int device) {
           py::list out;

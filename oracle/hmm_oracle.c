@@ -313,6 +313,178 @@ void fo_decode_batch(const fo_model* m, const uint8_t* obsBits, const uint8_t* h
   free(work);
 }
 
+/* ------------------------------------------------------------- the reference's scalar path */
+
+/* HMM::getNextAlpha (HMM.cpp:1611-1633): one pair, plain loops over the states */
+static void scalar_next_alpha(const fo_model* m, int row, float* alphaC, const float* previousAlpha, float* nextAlpha,
+                              const float* e1, const float* e0m1, const float* e2m0, float obsIsZero,
+                              float obsIsHomMinor)
+{
+  const int K = m->K;
+  alphaC[K - 1] = previousAlpha[K - 1];
+  for (int k = K - 2; k >= 0; k--) {
+    alphaC[k] = alphaC[k + 1] + previousAlpha[k];
+  }
+  const float* B = m->Bt + (size_t)row * K;
+  const float* U = m->Ut + (size_t)row * K;
+  const float* D = m->Dt + (size_t)row * K;
+  float AUc = 0;
+  for (int k = 0; k < K; k++) {
+    if (k) {
+      AUc = U[k - 1] * previousAlpha[k - 1] + m->colRatios[k - 1] * AUc;
+    }
+    float term = AUc + D[k] * previousAlpha[k];
+    if (k < K - 1) {
+      term += B[k] * alphaC[k + 1];
+    }
+    const float currentEmission_k = e1[k] + e0m1[k] * obsIsZero + e2m0[k] * obsIsHomMinor;
+    nextAlpha[k] = currentEmission_k * term;
+  }
+}
+
+/* HMM::getPreviousBeta (HMM.cpp:1692-1721).  BL and BU live across calls like the reference's vectors (zero
+ * initialised once: BL[0] and BU[K-1] are never written) */
+static void scalar_previous_beta(const fo_model* m, int row, const float* lastComputedBeta, float* BL, float* BU,
+                                 float* currentBeta, float* vec, const float* e1, const float* e0m1, const float* e2m0,
+                                 float obsIsZero, float obsIsHomMinor)
+{
+  const int K = m->K;
+  for (int k = 0; k < K; k++) {
+    const float currentEmission_k = e1[k] + e0m1[k] * obsIsZero + e2m0[k] * obsIsHomMinor;
+    vec[k] = lastComputedBeta[k] * currentEmission_k;
+  }
+  float sum = 0;
+  const float* B = m->Bt + (size_t)row * K;
+  for (int k = 1; k < K; k++) {
+    sum += B[k - 1] * vec[k - 1];
+    BL[k] = sum;
+  }
+  const float* U = m->Ut + (size_t)row * K;
+  const float* RR = m->RRt + (size_t)row * K;
+  for (int k = K - 2; k >= 0; k--) {
+    BU[k] = vec[k + 1] * U[k] + RR[k] * BU[k + 1];
+  }
+  const float* D = m->Dt + (size_t)row * K;
+  for (int k = 0; k < K; k++) {
+    currentBeta[k] = BL[k] + vec[k] * D[k] + BU[k];
+  }
+}
+
+/* HmmUtils.hpp:132-135 getSumOfVector (std::accumulate from 0) + 147-158 elementWiseMultVectorScalar with 1.f / sum */
+static void scalar_normalise(float* v, int K)
+{
+  float sum = 0;
+  for (int k = 0; k < K; k++) {
+    sum += v[k];
+  }
+  const float scaling = 1.f / sum;
+  for (int k = 0; k < K; k++) {
+    v[k] = v[k] * scaling;
+  }
+}
+
+void fo_decode_scalar(const fo_model* m, const uint8_t* obsBits, const uint8_t* homMinorBits, unsigned from,
+                      unsigned to, float* posterior)
+{
+  const int K = m->K;
+  const size_t S = (size_t)m->S;
+  float* alpha = (float*)calloc((size_t)K * S, sizeof(float)); /* [K][S], zero outside [from, to) */
+  float* beta = (float*)calloc((size_t)K * S, sizeof(float));
+  float* work = (float*)calloc((size_t)7 * K + 1, sizeof(float));
+  float* previous = work;         /* previousAlpha / lastComputedBeta */
+  float* next = work + K;         /* nextAlpha / currentBeta */
+  float* alphaC = work + 2 * K;   /* [K + 1] */
+  float* BL = work + 3 * K + 1;
+  float* BU = work + 4 * K + 1;
+  float* vec = work + 5 * K + 1;
+
+  /* ---- forward (HMM.cpp:1533-1609).  The first site's emission: the reference reads it from the emission tables
+   * (getEmission, 1509-1530); restated with the prepared rows of that site, which are those table values to an ulp
+   * (e1 exactly; e1 + (e0 - e1) and (e1 + (e0 - e1)) + (e2 - e0) for the homozygous classes, HMM.cpp:181-207) */
+  {
+    const float z = !obsBits[from] ? 1.0f : 0.0f, t = homMinorBits[from] ? 1.0f : 0.0f;
+    for (int k = 0; k < K; k++) {
+      const float emission = m->e1[(size_t)from * K + k] + m->e0m1[(size_t)from * K + k] * z +
+                             m->e2m0[(size_t)from * K + k] * t;
+      previous[k] = m->pi[k] * emission;
+    }
+    scalar_normalise(previous, K);
+    for (int k = 0; k < K; k++) {
+      alpha[(size_t)k * S + from] = previous[k];
+    }
+  }
+  for (unsigned pos = from + 1; pos < to; pos++) {
+    const float obsIsZero = !obsBits[pos] ? 1.0f : 0.0f;
+    const float obsIsHomMinor = homMinorBits[pos] ? 1.0f : 0.0f;
+    const float* e1 = m->e1 + (size_t)pos * K;
+    const float* e0m1 = m->e0m1 + (size_t)pos * K;
+    const float* e2m0 = m->e2m0 + (size_t)pos * K;
+    if (m->sequence) { /* HMM.cpp:1577-1588 */
+      const float* h = m->hom + (size_t)pos * K;
+      scalar_next_alpha(m, m->gapRowF[pos], alphaC, previous, next, h, h, h, 0.0f, 0.0f);
+      memcpy(previous, next, (size_t)K * sizeof(float));
+      scalar_next_alpha(m, m->siteRowF[pos], alphaC, previous, next, e1, e0m1, e2m0, obsIsZero, obsIsHomMinor);
+    } else {
+      scalar_next_alpha(m, m->stepRow[pos], alphaC, previous, next, e1, e0m1, e2m0, obsIsZero, obsIsHomMinor);
+    }
+    scalar_normalise(next, K); /* pos % scalingSkip == 0 with scalingSkip = 1 (HMM.cpp:1593-1598) */
+    for (int k = 0; k < K; k++) {
+      alpha[(size_t)k * S + pos] = next[k];
+      previous[k] = next[k];
+    }
+  }
+
+  /* ---- backward (HMM.cpp:1636-1690) ---- */
+  for (int k = 0; k < K; k++) {
+    previous[k] = 1.f;
+  }
+  scalar_normalise(previous, K);
+  for (int k = 0; k < K; k++) {
+    beta[(size_t)k * S + (to - 1)] = previous[k];
+    BL[k] = 0.f;
+    BU[k] = 0.f;
+  }
+  for (long pos = (long)to - 2; pos >= (long)from; pos--) {
+    const float obsIsZero = !obsBits[pos + 1] ? 1.0f : 0.0f;
+    const float obsIsHomMinor = homMinorBits[pos + 1] ? 1.0f : 0.0f;
+    const float* e1 = m->e1 + (size_t)(pos + 1) * K;
+    const float* e0m1 = m->e0m1 + (size_t)(pos + 1) * K;
+    const float* e2m0 = m->e2m0 + (size_t)(pos + 1) * K;
+    if (m->sequence) { /* HMM.cpp:1663-1675 */
+      const float* h = m->hom + (size_t)(pos + 1) * K;
+      scalar_previous_beta(m, m->gapRowB[pos + 1], previous, BL, BU, next, vec, h, h, h, 0.0f, 0.0f);
+      memcpy(previous, next, (size_t)K * sizeof(float));
+      scalar_previous_beta(m, m->siteRowB[pos + 1], previous, BL, BU, next, vec, e1, e0m1, e2m0, obsIsZero,
+                           obsIsHomMinor);
+    } else {
+      scalar_previous_beta(m, m->stepRow[pos + 1], previous, BL, BU, next, vec, e1, e0m1, e2m0, obsIsZero,
+                           obsIsHomMinor);
+    }
+    scalar_normalise(next, K);
+    for (int k = 0; k < K; k++) {
+      beta[(size_t)k * S + pos] = next[k];
+      previous[k] = next[k];
+    }
+  }
+
+  /* ---- posterior (HMM.cpp:1481-1482): element-wise product, then every column divided by its sum
+   * (normalizeMatrixColumns, HmmUtils.hpp:218-236: a DIVISION per element, where the batched path multiplies by a
+   * reciprocal).  Columns outside [from, to) are 0 / 0 in the reference; they are left 0 here. */
+  for (size_t pos = from; pos < to; pos++) {
+    float sum = 0;
+    for (int k = 0; k < K; k++) {
+      posterior[(size_t)k * S + pos] = alpha[(size_t)k * S + pos] * beta[(size_t)k * S + pos];
+      sum += posterior[(size_t)k * S + pos];
+    }
+    for (int k = 0; k < K; k++) {
+      posterior[(size_t)k * S + pos] = posterior[(size_t)k * S + pos] / sum;
+    }
+  }
+  free(work);
+  free(beta);
+  free(alpha);
+}
+
 /* ------------------------------------------------------------- consumers */
 
 /* HMM.cpp:1044-1085; note the loop covers all S sites */

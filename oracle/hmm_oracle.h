@@ -101,6 +101,19 @@ void fo_decode_batch(const fo_model* m, const uint8_t* obsBits, const uint8_t* h
                      unsigned to, float* alpha, float* beta, float* alphaFwd);
 
 /*
+ * The reference's SCALAR path for one pair -- HMM::decode (HMM.cpp:1469-1495) = forward (1533-1609, getNextAlpha
+ * 1611-1633) + backward (1636-1690, getPreviousBeta 1692-1721) + element-wise product and column normalisation
+ * (HmmUtils.hpp:132-244) -- "for debugging and pedagogical reasons" in the reference, and its own second
+ * implementation of the same mathematics: plain loops over the states, one pair, a division per posterior entry.
+ * A second statement of the chain inside the oracle: tests assert fo_decode_batch == fo_decode_scalar to 1e-5
+ * (the two differ in rounding only: reciprocal-multiply against division, the first site's emission from the prepared
+ * rows, see the source).  obsBits / homMinorBits: [S] bytes, absolute sites.  posterior: [K][S], caller-zeroed;
+ * columns outside [from, to) stay 0.
+ */
+void fo_decode_scalar(const fo_model* m, const uint8_t* obsBits, const uint8_t* homMinorBits, unsigned from,
+                      unsigned to, float* posterior);
+
+/*
  * HMM::augmentSumOverPairs (HMM.cpp:1044-1085).  obs vectors here are indexed by
  * absolute site (whole-sequence bits, as in non-hashing mode): [paddedB][S].
  * sum* are [S][K] row-major accumulators (any may be NULL when its flag is 0).

@@ -84,6 +84,8 @@ def lib():
         L.fo_calculate_scaling_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.fo_apply_scaling_batch.restype = None
         L.fo_apply_scaling_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.fo_decode_scalar.restype = None
+        L.fo_decode_scalar.argtypes = [C.POINTER(_FoModel), C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
         L.fo_decode_batch.restype = None
         L.fo_decode_batch.argtypes = [C.POINTER(_FoModel), C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_uint,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
@@ -393,6 +395,20 @@ def decode_batch(model: PreparedModel, obs_bits: np.ndarray, hom_bits: np.ndarra
     return (alpha, beta, afwd) if want_alpha_fwd else (alpha, beta)
 
 
+def decode_scalar(model: PreparedModel, obs_bits: np.ndarray, hom_bits: np.ndarray, frm: int = 0, to: int | None = None):
+    """The reference's scalar path for ONE pair (HMM::decode, HMM.cpp:1469-1495: forward 1533-1609, backward
+    1636-1690, product and column normalisation): the reference's own second implementation of the chain.
+    obs_bits / hom_bits: [S] uint8, absolute sites.  Returns the posterior [K][S] (columns outside [frm, to) zero)."""
+    ob = np.ascontiguousarray(obs_bits, np.uint8)
+    hb = np.ascontiguousarray(hom_bits, np.uint8)
+    to = model.S if to is None else to
+    assert ob.shape == hb.shape == (model.S,) and 0 <= frm < to <= model.S
+    post = np.zeros((model.K, model.S), np.float32)
+    m = model.c_struct()
+    lib().fo_decode_scalar(C.byref(m), _p(ob), _p(hb), frm, to, _p(post))
+    return post
+
+
 def ibd_scan_pair(model: PreparedModel, post: np.ndarray, v: int, frm: int, to: int, *, want_mean=True,
                   want_map=True, pair_ordinal=0, cap=4096) -> np.ndarray:
     out = np.zeros(cap, IBD_DTYPE)
@@ -497,6 +513,19 @@ def decode_pairs_ibd(model: PreparedModel, hap_bytes: np.ndarray, pairs, *, batc
 def _g7(x) -> str:
     """C++ ostream << with setprecision(7) (std::numeric_limits<float>::digits10 + 1), default float field."""
     return format(float(x), ".7g")
+
+
+def eigen_format_rows(mat) -> str:
+    """``matrix.format(Eigen::IOFormat(FullPrecision, DontAlignCols, " ", "\\n"))`` (HMM.hpp:154; used by
+    HMM::writePerPairOutput, HMM.cpp:1412-1420): coefficients of a row separated by a blank, rows by a newline --
+    BETWEEN rows: nothing follows the last one, so two matrices streamed one after the other share a line.
+    FullPrecision prints a float with NumTraits<float>::digits10() = 6 significant digits in the stream's general
+    notation (Eigen 3.4, what the reference's unpinned vcpkg dependency resolves to), i.e. "%.6g"; integers as they
+    are."""
+    a = np.asarray(mat)
+    if np.issubdtype(a.dtype, np.integer):
+        return "\n".join(" ".join(str(int(x)) for x in row) for row in a)
+    return "\n".join(" ".join("%.6g" % float(x) for x in row) for row in a)
 
 
 def format_ibd_text(recs: np.ndarray, pairs, fam_ids, iids, chr_number: int, phys, gen, *, want_length=True,

@@ -5,8 +5,10 @@ determinism).  C2 has its own file (test_gpu_full_size.py).
   C1  the reference's FASTSMC_EXAMPLE data (300 haplotypes x 6760 sites; tests/golden/fastsmc_example.*), job 7 of 9
       of the no-hashing regression shape (test_fastsmc_regression.cpp:97-161), synthetic map + 69-state model:
       FastSMC.run() text byte-identical to oracle + record formatter.
-  C3  the per-GPU shard shape of the 10 000 x 100 000 cohort: windows of 100 000 sites, K = 69 (49 chunks).
-  C4  K = 256, windows of 200 000 sites through the chunked wave-group kernel (four waves per group, lane = pair).
+  C3  the per-GPU shard shape of the 10 000 x 100 000 cohort: windows of 100 000 sites, K = 69 (49 chunks); 512
+      sampled pairs against the oracle.
+  C4  K = 256, windows of 200 000 sites through the chunked wave-group kernel (four waves per group, lane = pair);
+      128 sampled pairs against the oracle.
   C5  the hashing regime: 10 240 batches of 32 pairs, each with its own window of 320 ... 5504 sites.
 """
 import copy
@@ -45,8 +47,11 @@ def _invariants(rec, n_pairs, S):
     assert (score > 0).all() and (score <= 1.0 + 1e-5).all()
 
 
-def _whole_sequence_case(n_hap, S, K, n_pairs, n_sample, want_member, time=50, seed=1234):
-    """All-pairs-style list over whole-sequence windows: decode twice, check invariants, sample against the oracle."""
+def _whole_sequence_case(n_hap, S, K, n_pairs, n_sample, want_member, time=50, seed=1234, oracle_batch=32,
+                         oracle_threads=None):
+    """All-pairs-style list over whole-sequence windows: decode twice, check invariants, sample against the oracle (its
+    -mavx2 build, which tests/test_oracle_builds.py holds bit-identical to the checker build, one batch per host
+    thread; `oracle_batch` bounds a thread's two S x K x batch buffers -- per-pair results do not depend on it)."""
     tables = synth.make_model_tables(K)
     haps = synth.make_haps(n_hap, S, seed=seed)
     data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
@@ -77,13 +82,20 @@ def _whole_sequence_case(n_hap, S, K, n_pairs, n_sample, want_member, time=50, s
     assert rec.size > 20
     _invariants(rec, n_pairs, S)
     with_segments = np.unique(rec["pair"]).astype(np.int64)
-    sample = np.unique(np.concatenate([np.linspace(0, n_pairs - 1, n_sample // 2).astype(np.int64),
+    # n_sample pairs evenly spaced over the list, and a quarter as many again among the pairs that have segments
+    sample = np.unique(np.concatenate([np.linspace(0, n_pairs - 1, n_sample).astype(np.int64),
                                        with_segments[np.linspace(0, with_segments.size - 1,
-                                                                 n_sample - n_sample // 2).astype(np.int64)]]))
+                                                                 max(4, n_sample // 4)).astype(np.int64)]]))
     _, _, flipped = synth.fold_and_pack(haps.alleles)
     folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
-    want = O.decode_pairs_ibd(_oracle_model(pm), folded, [tuple(int(x) for x in pairs[i]) for i in sample],
-                              batch_size=32)
+    threads = oracle_threads or max(1, min(len(os.sched_getaffinity(0)), 16))
+    O.select_build("avx2")
+    try:
+        want = O.decode_pairs_ibd(_oracle_model(pm), folded, [tuple(int(x) for x in pairs[i]) for i in sample],
+                                  batch_size=oracle_batch, threads=threads)
+    finally:
+        O.select_build("ref")
+    assert sample.size >= n_sample
     got = rec[np.isin(rec["pair"], sample)]
     assert got.size == want.size and want.size > 0
     np.testing.assert_array_equal(got["pair"], sample[want["pair"]])
@@ -92,11 +104,14 @@ def _whole_sequence_case(n_hap, S, K, n_pairs, n_sample, want_member, time=50, s
 
 
 def test_c3_shard_shape_100k_sites():
-    _whole_sequence_case(n_hap=128, S=100000, K=69, n_pairs=4096, n_sample=24, want_member=69)
+    # 512 of the 4096 pairs against the oracle (16 pairs a batch: 14 GB of oracle buffers on 16 threads)
+    _whole_sequence_case(n_hap=128, S=100000, K=69, n_pairs=4096, n_sample=512, want_member=69, oracle_batch=16)
 
 
 def test_c4_256_states_200k_sites_chunked_wide_model_kernel():
-    _whole_sequence_case(n_hap=128, S=200000, K=256, n_pairs=2048, n_sample=8, want_member=1064, time=200)
+    # 128 of the 2048 pairs against the oracle (8 pairs a batch on 8 threads: 26 GB of oracle buffers, ~15 s)
+    _whole_sequence_case(n_hap=128, S=200000, K=256, n_pairs=2048, n_sample=128, want_member=1064, time=200,
+                         oracle_batch=8, oracle_threads=8)
 
 
 def test_c1_reference_example_data_job_7_of_9(tmp_path):

@@ -256,3 +256,33 @@ def test_hashing_parameters_are_checked(hash_files):
     p.constReadAhead = 0
     with pytest.raises(RuntimeError, match="constReadAhead"):
         api.hashingCandidates(data, p)
+
+
+def test_individuals_word_known_answers():
+    """TESTS/test_hashing.cpp:33-71 ("individuals"): with words of 8 sites, markers set at (word 0, bit 0), (word 1,
+    bit 2) and (word 2, bits 2 and 3) hash to 1, 4 and 12 -- `getWordString` "00000001", "00000100", "00001100" -- and
+    an untouched word to 0.  The product has no per-individual ring buffer (the reference's `Individuals` keeps
+    `numReadAhead` words and addresses them modulo that; `clear` wipes a slot for re-use): the identification step reads
+    whole words from the packed matrix, so what is pinned here is the word PACKER for hashingWordSize != 64 --
+    bit b of word w is the allele of site w * wordSize + b (FastSMC.cpp:176-186: setMarker(word, snp_ctr))."""
+    word_size, n_words = 8, 10  # ("check up to 10", test_hashing.cpp:41-45)
+    S = word_size * n_words + 5  # (+ an incomplete last word: never hashed, FastSMC.cpp:186-195)
+    alleles = np.zeros((6, S), np.uint8)
+    for word, bit in ((0, 0), (1, 2), (2, 2), (2, 3)):  # ind.setMarker(0, 0); setMarker(1, 2); setMarker(2, 2); setMarker(2, 3)
+        alleles[5, word * word_size + bit] = 1          # (idNum 5, test_hashing.cpp:35)
+    bp = np.arange(1, S + 1, dtype=np.int64) * 1000
+    cm = bp * 1e-6
+    data = api.Data.from_arrays(alleles, bp, cm, False, True)  # (no folding: a bit is the file's allele)
+    p = api.DecodingParams()
+    p.hashingWordSize = word_size
+    words = api.hashingWords(data, p)
+    assert words.shape == (6, n_words) and words.dtype == np.uint64
+    assert [int(x) for x in words[5, :3]] == [1, 4, 12]                      # getWordHash(0 / 1 / 2)
+    strings = [format(int(x), f"0{word_size}b") for x in words[5, :3]]     # boost::to_string: highest bit first
+    assert strings == ["00000001", "00000100", "00001100"]
+    assert not words[5, 3:].any() and not words[:5].any()                     # getWordHash(i) == 0, "00000000"
+    # the default word size takes the packed genotype words as they are
+    p.hashingWordSize = 64
+    w64 = api.hashingWords(data, p)
+    assert w64.shape == (6, S // 64)
+    assert int(w64[5, 0]) == (1 << 0) | (1 << 10) | (1 << 18) | (1 << 19)

@@ -185,3 +185,43 @@ def test_sequence_mode_files_round_trip(seq_problem, tmp_path):
                            no_conditional_age_estimates=p.noConditionalAgeEstimates)
     _assert_same_model(got, want)
     _assert_same_sequence_rows(got, want)
+
+
+def test_expected_coal_times_file_is_read_like_the_reference(tmp_path):
+    """HMM.cpp:43-61, 1736-1748: the second column of the intervals file replaces the decoding quantities' expected
+    times in ASMC mode; a line without three fields is an error (the reference exits with this message); FastSMC mode
+    never reads the file.  No GPU involved: the engine opens at the first decode."""
+    import numpy as np
+    import pytest
+    from fastsmc_amd import api, synth
+
+    tables = synth.make_model_tables(12)
+    haps = synth.make_haps(64, 60, seed=3)
+    data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
+    dq = api.decoding_quantities_from_tables(tables)
+    K = len(tables.expected_times)
+    good = str(tmp_path / "good.intervalsInfo")
+    custom = np.linspace(5.0, 5000.0, K).astype(np.float32)
+    with open(good, "w") as f:
+        for k in range(K):
+            f.write(f"{k}\t{float(custom[k])!r}\t{k + 1}\n")
+    p = api.DecodingParams()
+    p.FastSMC = False
+    p.expectedCoalTimesFile = good
+    np.testing.assert_array_equal(np.array(api.HMM(data, dq, p).getExpectedCoalTimes(), np.float32), custom)
+    p.expectedCoalTimesFile = str(tmp_path / "missing")   # not a regular file: the decoding quantities' times
+    np.testing.assert_array_equal(np.array(api.HMM(data, dq, p).getExpectedCoalTimes(), np.float32),
+                                  np.asarray(tables.expected_times, np.float32))
+    bad = str(tmp_path / "bad.intervalsInfo")
+    open(bad, "w").write("0\t1.5\t2\n3 4\n")
+    p.expectedCoalTimesFile = bad
+    with pytest.raises(RuntimeError, match="intervalStart"):
+        api.HMM(data, dq, p)
+    short = str(tmp_path / "short.intervalsInfo")
+    open(short, "w").write("0\t1.5\t2\n")
+    p.expectedCoalTimesFile = short
+    with pytest.raises(RuntimeError, match="intervals"):
+        api.HMM(data, dq, p)
+    p.FastSMC = True
+    p.expectedCoalTimesFile = bad
+    api.HMM(data, dq, p)  # FastSMC mode does not look at it
