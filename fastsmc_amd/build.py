@@ -19,7 +19,7 @@ HIPCC_FLAGS = [
 
 # family members of the library (csrc/fsmc_instances.h): one translation unit each, compiled in parallel
 KT_MEMBERS = [16, 32, 48, 64, 69, 80, 96, 112, 128]
-W2_MEMBERS = [48, 64]
+W2_MEMBERS = [48, 64, 80, 96, 112]
 OBJ_DIR = os.path.join(CSRC, "obj")
 
 

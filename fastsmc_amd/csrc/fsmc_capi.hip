@@ -297,11 +297,13 @@ bool halfAvailable(int mode, const fsmc_model* m)
   return mode == kModeIbd && !m->sequence && halfBuilt(familyMember(m));
 }
 
-// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): 128 < K <= 256, every consumer,
-// array and sequence mode.  fsmc_model_create pads such a model's rows to KP = 192 or 256 floats = 4 x the states per wave.
+// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): 128 < K <= 448, every consumer,
+// array and sequence mode.  fsmc_model_create pads such a model's rows to KP = 4 x the states per wave of the member:
+// 192 or 256 floats (two workgroups per CU), 320, 384 or 448 (one workgroup per CU: 80, 96, 112 states a wave).
 bool waveGroups(int mode, const fsmc_model* m)
 {
-  return familyMember(m) == 0 && m->K > 128 && m->K <= 256 && (m->KP == 192 || m->KP == 256) &&
+  return familyMember(m) == 0 && m->K > 128 && m->K <= kMaxStatesW2 &&
+         (m->KP == 192 || m->KP == 256 || m->KP == 320 || m->KP == 384 || m->KP == 448) &&
          (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair);
 }
 
@@ -329,10 +331,10 @@ unsigned blockThreads(int mode, const fsmc_model* m)
   return waveGroups(mode, m) ? (unsigned)(kW2NW * kWave) : (unsigned)kWave;
 }
 
-// more than 256 states: the any-K kernel (fsmc_kernels_any.h)
+// more than 448 states: the any-K kernel (fsmc_kernels_any.h)
 bool anyStates(const fsmc_model* m)
 {
-  return m->K > kMaxStates;
+  return m->K > kMaxStatesW2;
 }
 
 template <bool SEQ> KernelFn pickAnyKernel(int mode, bool track)
@@ -364,9 +366,19 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
     if (mode == kModeIbd) {
       m->ctx->lastStride = 1;
     }
-    m->ctx->lastMember = 1000 + m->KP / kW2NW; // 1048 / 1064: four waves per group, 48 / 64 states per wave
-    return m->KP == 192 ? pickWaveGroupKernel<48>(mode, track, m->sequence != 0)
-                        : pickWaveGroupKernel<64>(mode, track, m->sequence != 0);
+    m->ctx->lastMember = 1000 + m->KP / kW2NW; // 1048 ... 1112: four waves per group, 48 ... 112 states per wave
+    switch (m->KP / kW2NW) {
+    case 48:
+      return pickWaveGroupKernel<48>(mode, track, m->sequence != 0);
+    case 64:
+      return pickWaveGroupKernel<64>(mode, track, m->sequence != 0);
+    case 80:
+      return pickWaveGroupKernel<80>(mode, track, m->sequence != 0);
+    case 96:
+      return pickWaveGroupKernel<96>(mode, track, m->sequence != 0);
+    default:
+      return pickWaveGroupKernel<112>(mode, track, m->sequence != 0);
+    }
   }
   const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1; // (also with two half-groups per wave)
   if (mode == kModeIbd) {
@@ -1006,9 +1018,9 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   m->ctx = ctx;
   m->K = d->K;
   m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
-  if (d->K > 128 && d->K <= kMaxStates) {
+  if (d->K > 128 && d->K <= kMaxStatesW2) {
     // wide models: four waves per group hold KP/4 states each (fsmc_kernels_w2.h); the padding states are ghosts
-    m->KP = d->K <= 192 ? 192 : 256;
+    m->KP = d->K <= 192 ? 192 : d->K <= 256 ? 256 : d->K <= 320 ? 320 : d->K <= 384 ? 384 : 448;
   }
   m->S = d->S;
   m->nRows = d->n_rows;

@@ -81,7 +81,7 @@ constexpr bool halfBuilt(const int KT)
 
 // every member of the library (build.py compiles fsmc_inst.hip once for each entry of these two lists)
 #define FSMC_ALL_KT(Y) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80) Y(96) Y(112) Y(128)
-#define FSMC_ALL_W2(Y) Y(48) Y(64)
+#define FSMC_ALL_W2(Y) Y(48) Y(64) Y(80) Y(96) Y(112)
 
 #if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_W2)
 #define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)

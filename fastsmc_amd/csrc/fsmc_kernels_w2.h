@@ -120,7 +120,7 @@ __device__ __forceinline__ void rowInPieces(const RowIO& io, const int first, co
 // hit.  (The outer waves' first pass is phase 0: nothing to hide behind.  Warming it during the sum of the step before
 // was measured: the requests outlast the sum and the step got longer.)
 template <int KH, int KP, int R0, int R1 = -1, int R2 = -1, int R3 = -1> struct WarmRows {
-  static constexpr int kLines = KH / 16;
+  static constexpr int kLines = KH / 16 < 4 ? KH / 16 : 4; // (a Touched holds four lines: the first four of a wider part)
   Touched t0, t1, t2, t3;
   __device__ __forceinline__ void request(cfloat_p rsw)
   {
@@ -147,17 +147,24 @@ struct W2Ctx {
 
 // Sum of all states in state order (HmmUtils.cpp:121-128): wave 0 adds its states from 0.f, every next wave continues.
 // NW barriers; returns the total in every wave.  `row`: first of NW mailbox rows.
-template <int KH, int H>
+// FIRST = 1: wave 0's partial sum is in the mailbox already, published by the barrier the caller has just passed (the
+// step functions: wave 0's row is final at the end of the step's last phase, so it adds its states before that
+// phase's barrier instead of behind it -- one hand-over less per step).
+template <int KH, int H> __device__ __forceinline__ float w2PartialSum(const float (&v)[KH], float s)
+{
+#pragma unroll
+  for (int k = 0; k < KH; ++k) {
+    s = s + v[k];
+  }
+  return s;
+}
+template <int KH, int H, int FIRST = 0>
 __device__ __forceinline__ float w2OrderedTotal(const W2Ctx& cx, const float (&v)[KH], const int row)
 {
 #pragma unroll
-  for (int ph = 0; ph < kW2NW; ++ph) {
+  for (int ph = FIRST; ph < kW2NW; ++ph) {
     if (H == ph) {
-      float s = ph == 0 ? 0.f : cx.mail[(row + ph - 1) * kWave + cx.lane];
-#pragma unroll
-      for (int k = 0; k < KH; ++k) {
-        s = s + v[k];
-      }
+      const float s = w2PartialSum<KH, H>(v, ph == 0 ? 0.f : cx.mail[(row + ph - 1) * kWave + cx.lane]);
       cx.mail[(row + ph) * kWave + cx.lane] = s;
     }
     if (ph == kW2NW - 1) {
@@ -168,6 +175,11 @@ __device__ __forceinline__ float w2OrderedTotal(const W2Ctx& cx, const float (&v
   }
   return cx.mail[(row + kW2NW - 1) * kWave + cx.lane];
 }
+#if defined(FSMC_W2_NO_MERGED_SUM) // (A/B switch: the separate first hand-over of round 3)
+constexpr int kW2SumFirst = 0;
+#else
+constexpr int kW2SumFirst = 1;
+#endif
 
 // v = w * (1.0f / total) (HmmUtils.cpp:102-151)
 template <int KH> __device__ __forceinline__ void w2Scale(float (&v)[KH], const float (&w)[KH], const float total)
@@ -191,8 +203,10 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
 {
   FSMC_END(dg, 20); // (region stamps, diagnostic builds: 0-3 work of the phases, 4-7 their barriers, 8 sum, 9 scale)
   constexpr int KP = kW2NW * KH;
-  constexpr int kLines = KH / 16; // 64-byte lines of this wave's part of a table row
-  static_assert(KH % kWBWide == 0 && KH % 16 == 0 && kLines <= 4, "whole operand blocks and lines");
+  // 64-byte lines of this wave's part of a table row that the warm-up touches (a Touched holds four; the members of
+  // more than 64 states a wave warm the first lines of their part only)
+  constexpr int kLines = KH / 16 < 4 ? KH / 16 : 4;
+  static_assert(KH % kWBWide == 0 && KH % 16 == 0, "whole operand blocks and lines");
   long long dummy = 0;
   (void)dummy;
   constexpr int off = H * KH;  // first state of this wave
@@ -400,6 +414,11 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
     if (outer && ph == 1) {
       warmOuter.request(rsw);
     }
+    if constexpr (SCALE && kW2SumFirst == 1 && H == 0) {
+      if (ph == kW2NW - 1) { // wave 0's row is final: its share of the ordered sum rides on this phase's barrier
+        cx.mail[kW2RowStep * kWave + cx.lane] = w2PartialSum<KH, H>(w, 0.f);
+      }
+    }
     FSMC_END(dg, ph);
     w2PhaseBarrier();
     if (!outer && ph == 0) {
@@ -411,7 +430,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
     FSMC_END(dg, 4 + ph);
   }
   if constexpr (SCALE) {
-    const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
+    const float total = w2OrderedTotal<KH, H, kW2SumFirst>(cx, w, kW2RowStep);
     FSMC_END(dg, 8);
     w2Scale<KH>(b, w, total);
     FSMC_END(dg, 9);
@@ -431,8 +450,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
   FSMC_END(dg, 21); // (10-13 work of the phases, 14-17 their barriers, 18 sum, 19 scale)
   constexpr int KP = kW2NW * KH;
   constexpr int NBF = KH / kWBF;
-  constexpr int kLines = KH / 16;
-  static_assert(KH % kWBF == 0 && KH % 16 == 0 && kLines <= 4, "whole operand blocks and lines");
+  constexpr int kLines = KH / 16 < 4 ? KH / 16 : 4;
+  static_assert(KH % kWBF == 0 && KH % 16 == 0, "whole operand blocks and lines");
   typedef typename SV<kWBF>::T SVec;
   long long dummy = 0;
   (void)dummy;
@@ -600,12 +619,18 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
       // the next beta row is requested in the phases a wave would spend at the barrier: the outer waves work in phases
       // 0 and 3, the inner ones in phases 1 and 2 -- half a row in each idle phase (the combine is a sum pass away)
       constexpr bool outer = H == 0 || H == kW2NW - 1;
+#if defined(FSMC_W2_ROWIN_EARLY) // (experiment: the whole row in a wave's FIRST idle phase)
+      if ((outer && ph == 1) || (!outer && ph == 0)) {
+        rowInPieces(in, 0, KH / 4);
+      }
+#else
       if ((outer && ph == 1) || (!outer && ph == 0)) {
         rowInPieces(in, 0, KH / 8);
       }
       if ((outer && ph == 2) || (!outer && ph == 3)) {
         rowInPieces(in, KH / 8, KH / 4 - KH / 8);
       }
+#endif
     }
     // idle-phase warm-up (WarmRows): wave 1 reads D, U in phase 1 and B in phase 2, wave 2 D, U, B in phase 2 -- both sit
     // out phase 0; wave 0 reads B and wave 3 D, U, B in phase 3 -- both sit out phase 1 (the column ratios are one row for
@@ -619,6 +644,11 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     if (outerA && ph == 1) {
       warmOuter.request(rsw);
     }
+    if constexpr (SCALE && kW2SumFirst == 1 && H == 0) {
+      if (ph == kW2NW - 1) { // (as in the backward step: wave 0's share of the ordered sum rides on this barrier)
+        cx.mail[kW2RowStep * kWave + cx.lane] = w2PartialSum<KH, H>(w, 0.f);
+      }
+    }
     FSMC_END(dg, 10 + ph);
     w2PhaseBarrier();
     if (!outerA && ph == 0) {
@@ -630,7 +660,7 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     FSMC_END(dg, 14 + ph);
   }
   if constexpr (SCALE) {
-    const float total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep);
+    const float total = w2OrderedTotal<KH, H, kW2SumFirst>(cx, w, kW2RowStep);
     FSMC_END(dg, 18);
     w2Scale<KH>(a, w, total);
     FSMC_END(dg, 19);
@@ -662,15 +692,30 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 #ifndef FSMC_W2_WG_PER_CU
 #define FSMC_W2_WG_PER_CU 2
 #endif
+// Members of more than 64 states a wave (KH = 80 ... 128: models of 257 ... 512 states) run ONE workgroup per CU: their
+// landing zones alone are 80 ... 128 KiB of the CU's 160, and a wave has the whole 512-entry register file (256
+// registers + accumulation registers for what the allocator has to park).
+constexpr int w2WorkgroupsPerCU(int KH) { return KH <= 64 ? FSMC_W2_WG_PER_CU : 1; }
 template <int KH, int MODE, bool TRACK, bool SEQ = false>
-__global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kernel_w2(const KParams p)
+__global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_kernel_w2(const KParams p)
 {
   static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums || MODE == kModePerPair,
                 "the consumers of the wave-group kernel");
   constexpr int KP = kW2NW * KH;
   constexpr int K4H = KH / 4;        // float4 per lane of this wave's part of a K-vector
   constexpr int NC = SEQ ? 4 : 3;    // emission rows per site: three observation classes (+ the gap's homozygous row)
-  constexpr int E4H = NC * K4H;      // float4 of one site's emission values of this wave's states
+  // The rows of the three observation classes lie one float4 further apart than their length (array mode): K4H * 16 B is
+  // a multiple of the LDS bank window, so lanes of different classes reading "their" row at the same state index hit
+  // the same banks -- a three-way conflict on every emission read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 30 % in
+  // round 3's counters); one float4 of padding per row spreads the classes over different banks.  The padding lane of
+  // a row's LDS-DMA request reads the row's last float4 again.  (Sequence mode keeps the dense layout: four padded rows
+  // would need a second request per site.)
+#if defined(FSMC_W2_NO_EMIS_PAD) // (A/B switch)
+  constexpr int ERS = K4H;
+#else
+  constexpr int ERS = SEQ ? K4H : K4H + 1; // float4 between the rows of two classes in a ring slot
+#endif
+  constexpr int E4H = NC * ERS;      // float4 of one site's emission values of this wave's states (+ padding)
   constexpr int NLE = (E4H + kWave - 1) / kWave;
   __shared__ float4 emisLds[kW2NW][2][E4H];       // [wave][ring slot][class * K4H + k4]
   __shared__ float4 betaLds[kW2NW][K4H * kWave];  // [wave]: landing zone of the next site's beta row (its part)
@@ -793,7 +838,8 @@ __global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kerne
       for (int i = 0; i < NLE; ++i) {
         const int idx = lane + i * kWave; // class * K4H + k4
         if (idx < E4H) {
-          const int cls = idx / K4H, k4 = idx - cls * K4H;
+          const int cls = idx / ERS, k4r = idx - cls * ERS;
+          const int k4 = k4r < K4H ? k4r : K4H - 1; // (the padding lane)
           const float4* src = p.emis3 + (size_t)q * (NC * (KP / 4)) + (size_t)cls * (KP / 4) + h * K4H + k4;
           dmaToLds((gf32x4_p)src, &emisLds[h][q & 1][i * kWave]);
         }
@@ -873,7 +919,7 @@ __global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kerne
       constexpr bool OUT = decltype(moveRow)::value;
       const int c = obsClass(q);
       const cfloat_p rsq = rowSetOfRow(SEQ ? __builtin_amdgcn_readfirstlane(p.rowSiteB[q]) : stepRowOf(q));
-      const float4* eq = &emisLds[h][q & 1][c * K4H];
+      const float4* eq = &emisLds[h][q & 1][c * ERS];
       const RowIO out = {OUT ? uniformPtr(outRow + halfF4) : (gchar_p) nullptr, laneOff, nullptr};
       FSMC_W2_ROLE(h, (beta_step_w2<KH, H, true, OUT>(cx, b, w, rsq, eq, ghostMask, cycW, out)));
     };
@@ -884,7 +930,7 @@ __global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kerne
     // (the fourth row of its ring slot)
     auto betaGapStep = [&](float (&b)[KH], float (&w)[KH], const int q) {
       const cfloat_p rsq = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapB[q]));
-      const float4* eq = &emisLds[h][q & 1][3 * K4H];
+      const float4* eq = &emisLds[h][q & 1][3 * ERS];
       FSMC_W2_ROLE(h, (beta_step_w2<KH, H, false>(cx, b, w, rsq, eq, ghostMask, cycW, noRowIO())));
     };
     // the site step out of q = pos+1 (its rows are in the ring), then the half-step towards pos-1 unless pos is the
@@ -1090,7 +1136,7 @@ __global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kerne
       waitVm0();
       for (int pos = lo; pos < hi; ++pos) {
         const int c = obsClass(pos);
-        const float4* e = &emisLds[h][pos & 1][c * K4H];
+        const float4* e = &emisLds[h][pos & 1][c * ERS];
         if (__builtin_expect(pos == from, 0)) {
           // alpha at the first site: pi * emission, scaled (HMM.cpp:736-747)
 #pragma unroll
@@ -1125,7 +1171,7 @@ __global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kerne
             waitVm0(); // the rows of site pos + 1 (requested a site ago) have landed
             __builtin_amdgcn_wave_barrier();
             const cfloat_p rsg = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapF[pos + 1]));
-            const float4* eg = &emisLds[h][(pos + 1) & 1][3 * K4H];
+            const float4* eg = &emisLds[h][(pos + 1) & 1][3 * ERS];
             FSMC_W2_ROLE(h, (alpha_step_w2<KH, H, false>(cx, a, w, rsg, tCR, eg, cycW, noRowIO())));
           }
         }
@@ -1204,37 +1250,42 @@ __global__ __launch_bounds__(kW2NW * kWave, FSMC_W2_WG_PER_CU) void decode_kerne
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           waitLgkm0();
           __builtin_amdgcn_wave_barrier();
-          const int state = h * KH + lane;
-          if (lane < KH && state < K) {
-            float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + state;
-            float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
-            if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
-              if (p.flags & FSMC_WANT_SUMS) s = acc[0];
-              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                s00 = acc[p.sumsPlane];
-                s01 = acc[2 * p.sumsPlane];
-                s11 = acc[3 * p.sumsPlane];
-              }
-            }
-            for (int v = 0; v < nPairsInGroup; ++v) {
-              const float q = tile[lane * kWave + ((v + lane) & (kWave - 1))];
-              s = s + q;
-              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                const int cv = clsLds[h][v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
-                if (cv == 2) {
-                  s11 = s11 + q;
-                } else if (cv == 1) {
-                  s00 = s00 + q;
-                } else {
-                  s01 = s01 + q;
+          // lane j owns state j of every 64 of this wave's states (a wave of more than 64 states takes two turns)
+#pragma unroll
+          for (int base = 0; base < KH; base += kWave) {
+            const int kLocal = base + lane;
+            const int state = h * KH + kLocal;
+            if (kLocal < KH && state < K) {
+              float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + state;
+              float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
+              if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
+                if (p.flags & FSMC_WANT_SUMS) s = acc[0];
+                if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                  s00 = acc[p.sumsPlane];
+                  s01 = acc[2 * p.sumsPlane];
+                  s11 = acc[3 * p.sumsPlane];
                 }
               }
-            }
-            if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
-            if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-              acc[p.sumsPlane] = s00;
-              acc[2 * p.sumsPlane] = s01;
-              acc[3 * p.sumsPlane] = s11;
+              for (int v = 0; v < nPairsInGroup; ++v) {
+                const float q = tile[kLocal * kWave + ((v + kLocal) & (kWave - 1))];
+                s = s + q;
+                if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                  const int cv = clsLds[h][v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
+                  if (cv == 2) {
+                    s11 = s11 + q;
+                  } else if (cv == 1) {
+                    s00 = s00 + q;
+                  } else {
+                    s01 = s01 + q;
+                  }
+                }
+              }
+              if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
+              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                acc[p.sumsPlane] = s00;
+                acc[2 * p.sumsPlane] = s01;
+                acc[3 * p.sumsPlane] = s11;
+              }
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -483,6 +483,7 @@ void HMM::resetDecoding()
 {
   // HMM.cpp:259-271: the per-pair text outputs of ASMC mode are (re)opened here
   closePerPairFiles();
+  mPerPairRows = 0;
   auto openOut = [&](const std::string& suffix) {
     const std::string name = mParams.outFileRoot + suffix;
     gzFile f = gzopen(name.c_str(), "w");
@@ -774,7 +775,7 @@ void HMM::flush()
       auto writeRows = [&](gzFile f, auto&& cell) {
         text.clear();
         for (size_t i = 0; i < nPairs; ++i) {
-          if ((mPairsFlushed + i) % B != 0) {
+          if ((mPerPairRows + i) % B != 0) {
             text.push_back('\n');
           }
           for (size_t pos = 0; pos < S; ++pos) {
@@ -796,6 +797,7 @@ void HMM::flush()
       if (mMapFile) {
         writeRows(mMapFile, [&](char* b, size_t n, size_t idx) { return std::snprintf(b, n, "%d", map[idx]); });
       }
+      mPerPairRows += nPairs;
     }
     for (size_t i = 0; storeAny && i < nPairs; ++i) {
       const auto [indA, hapA] = hapToDipId(mPairs[i].hap_a);

@@ -208,6 +208,7 @@ private:
   bool mStoreMean = false, mStoreMap = false, mStorePosterior = false, mStoreSumOfPosterior = false;
   bool mWriteMean = false, mWriteMap = false;
   gzFile mMeanFile = nullptr, mMapFile = nullptr;
+  uint64_t mPerPairRows = 0; // rows written to the per-pair files since they were opened (batch boundaries)
   void closePerPairFiles();
   bool mKeepRecords = false;
   std::vector<fsmc_ibd_record> mKeptRecords;

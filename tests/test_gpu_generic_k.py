@@ -23,22 +23,24 @@ def _problem(K, n_hap=64, S=200, seed=11):
 
 
 def _member(K, consumer="ibd"):
-    """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; up to 256 the four-waves-per-group
-    kernel (1000 + states per wave); beyond, 0 = the any-K kernel (a pair's K-vectors in the workspace)."""
+    """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; up to 448 the four-waves-per-group
+    kernel (1000 + states per wave: 48 / 64 with two workgroups per CU, 80 / 96 / 112 with one); beyond, 0 = the any-K
+    kernel (a pair's K-vectors in the workspace)."""
     if K == 69:
         return 69
     if K <= 128:
         return (K + 15) // 16 * 16
-    if K > 256:
+    if K > 448:
         return 0
-    return 1000 + (48 if K <= 192 else 64)
+    return 1000 + (48 if K <= 192 else 64 if K <= 256 else 80 if K <= 320 else 96 if K <= 384 else 112)
 
 
 def _stride(K):
     return 2 if K <= 128 else 1  # every member of the lane-per-pair family is built with beta stride 2
 
 
-@pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 50, 64, 65, 70, 80, 81, 100, 128, 130, 192, 200, 256, 257, 300, 402])
+@pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 50, 64, 65, 70, 80, 81, 100, 128, 130, 192, 200, 256, 257, 300, 320, 321,
+                               402, 448, 449, 520])
 def test_generic_kernel_matches_oracle(K):
     pm, bits, folded = _problem(K)
     pairs = O.enumerate_all_pairs(32)[:96]
@@ -74,7 +76,7 @@ def test_generic_kernel_matches_oracle(K):
     wsum = np.zeros((pm.S, pm.K), np.float32)
     O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
     np.testing.assert_array_equal(s, wsum)
-    if K in (5, 100, 200, 256, 300):  # the 00 / 01 / 11 split in one member of each kernel
+    if K in (5, 100, 200, 256, 300, 402, 520):  # the 00 / 01 / 11 split in one member of each kernel
         s2, mm = ctx.decode_sums(model, major_minor=True)
         want = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
         O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, want[0], want[1], want[2], want[3])
@@ -138,8 +140,8 @@ def test_wide_model_scan_thresholds_that_reach_the_upper_waves(K, time):
 
 
 def test_too_many_states_is_rejected():
-    """Up to 256 states a kernel holds a pair's vectors in registers; beyond, the any-K kernel keeps them in the workspace
-    (tested above: 257, 300, 402 states); the library's limit is 4096."""
+    """Up to 448 states a kernel holds a pair's vectors in registers; beyond, the any-K kernel keeps them in the workspace
+    (tested above: 449 and 520 states); the library's limit is 4096."""
     pm, bits, _ = _problem(16)
     ctx = capi.Context(0)
     import copy
@@ -153,11 +155,13 @@ def test_too_many_states_is_rejected():
     ctx.close()
 
 
-@pytest.mark.parametrize("K", [300])
-def test_any_k_kernel_windows_chunks_and_thresholds(K):
-    """The any-K kernel through the checkpoint / rebuild layout (explicit chunk lengths that do and do not divide the
-    windows), windows whose scan ends before the decode window does, one- and two-site windows, ragged groups, with and
-    without segment ages, and a time threshold that puts the scan's state threshold beyond 256."""
+@pytest.mark.parametrize("K", [300, 402, 500])
+def test_beyond_256_states_windows_chunks_and_thresholds(K):
+    """Models of more than 256 states -- 300 and 402: the wave-group kernel with 80 / 112 states a wave, one workgroup per
+    CU; 500: the any-K kernel -- through the checkpoint / rebuild layout (explicit chunk lengths that do and do not
+    divide the windows), windows whose scan ends before the decode window does, one- and two-site windows, ragged
+    groups, with and without segment ages, and a time threshold that puts the scan's state threshold beyond 256 (the
+    scan's sum then walks all four waves of a group)."""
     tables = synth.make_model_tables(K)
     haps = synth.make_haps(64, 333, seed=K, cm_per_mb=25.0, switch_per_cm=0.6)
     bits, derived, flipped = synth.fold_and_pack(haps.alleles)
@@ -197,7 +201,7 @@ def test_any_k_kernel_windows_chunks_and_thresholds(K):
             if chunk:
                 ctx.set_chunk_sites(chunk)
             got = ctx.decode_ibd(model, pr, groups, flags)
-            assert ctx.last_kernel() == 0 and (ctx.info()["max_chunks"] > 1) == bool(chunk)
+            assert ctx.last_kernel() == _member(K) and (ctx.info()["max_chunks"] > 1) == bool(chunk)
             ctx.close()
             assert got.size == want.size
             for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"),

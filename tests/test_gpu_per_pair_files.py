@@ -41,7 +41,8 @@ def test_decode_all_writes_the_per_pair_files(small_problem, tmp_path, batch):
     p = api.DecodingParams(root, root + ".decodingQuantities.gz")
     p.useKnownSeed = True
     p.batchSize = batch
-    p.jobs, p.jobInd = 9, 4
+    p.outFileRoot = root
+    p.jobs, p.jobInd = 4, 2
     data = api.Data(p)
     hmm = api.HMM(data, p)
     hmm.setWritePerPairPosteriorMean(True)
@@ -50,7 +51,7 @@ def test_decode_all_writes_the_per_pair_files(small_problem, tmp_path, batch):
     got_mean = gzip.open(root + ".perPairPosteriorMeans.gz", "rt").read()
     got_map = gzip.open(root + ".perPairMAP.gz", "rt").read()
     pm = _oracle_model(sp, data, p)
-    pairs = O.enumerate_all_pairs(32, 9, 4)
+    pairs = O.enumerate_all_pairs(32, 4, 2)
     assert len(pairs) % batch != 0 and len(pairs) > 2 * batch  # a ragged last batch, several batches
     want_mean, want_map = "", ""
     for chunk, post in _batches(sp, pm, pairs, batch):
