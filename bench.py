@@ -470,8 +470,12 @@ def main() -> None:
             if ref and ref.get("workload_key") == workload_key:
                 out["config"]["n1_pairs_per_s_same_worklist"] = ref["value"]
                 out["config"]["speedup_vs_n1"] = value / ref["value"]
+        # the extra measurements ride on the DEFAULT line only: any option that shapes the workload or the plan makes
+        # the run a measurement of its own
         default_line = (world == 1 and args.workload == "auto" and not args.no_other_workloads
-                        and not args.diag_same_row)
+                        and not args.diag_same_row and not args.haps and not args.sites and args.states == 69
+                        and args.flags < 0 and not args.chunk_sites and not args.beta_stride
+                        and args.resident_chunks < 0 and not args.force_collective)
         if default_line:
             out["config"]["other_workloads"] = other_workloads(ctx, capi, flags, budget_s=60.0)
         if default_line and args.ws_frac:

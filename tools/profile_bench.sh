@@ -8,7 +8,8 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$GRAFT_REPO_ROOT/bench.py $*"
+# (the headline kernel alone: the default line's other workloads launch kernels of the same name)
+ARGS="$GRAFT_REPO_ROOT/bench.py --no-other-workloads $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_under_trace.json 2> $OUT/trace.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $ARGS --cpu-pairs 0 > $OUT/bench_under_pmc_$C.json 2> $OUT/pmc_$C.err
