@@ -19,6 +19,10 @@ HIPCC_FLAGS = [
 
 # family members of the library (csrc/fsmc_instances.h): one translation unit each, compiled in parallel
 KT_MEMBERS = [16, 32, 48, 64, 69, 80, 96, 112, 128]
+# exact (ghost-free) members beside the 69-state one (csrc/fsmc_instances.h, FSMC_EXACT_KT): a model of exactly that many
+# states pays for no padding.  FSMC_EXACT_MEMBERS="50 100 75" in the environment of a build lists others (none a multiple
+# of 16, each <= 128 states); the list is part of the library's source hash.
+EXACT_MEMBERS = [int(x) for x in os.environ.get("FSMC_EXACT_MEMBERS", "50 100").split()]
 W2_MEMBERS = [48, 64, 80, 96, 112]
 OBJ_DIR = os.path.join(CSRC, "obj")
 
@@ -43,27 +47,40 @@ def hip_source_hash() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    h.update(" ".join(HIPCC_FLAGS).encode())  # (a build with other flags is another library)
+    h.update(" ".join(HIPCC_FLAGS + exact_define()).encode())  # (a build with other flags or members is another library)
     for s in hip_sources():
         h.update(os.path.basename(s).encode())
         h.update(open(s, "rb").read())
     return h.hexdigest()[:16]
 
 
+def exact_define() -> list[str]:
+    """-D for a list of exact members other than the header's default."""
+    if EXACT_MEMBERS == [50, 100]:
+        return []
+    bad = [k for k in EXACT_MEMBERS if k % 16 == 0 or not 0 < k <= 128 or k == 69]
+    if bad:
+        raise ValueError(f"FSMC_EXACT_MEMBERS: {bad} -- an exact member has 1..128 states, not a multiple of 16 (69 is built in)")
+    return ["-DFSMC_EXACT_KT(Y)=" + " ".join(f"Y({k})" for k in EXACT_MEMBERS)]
+
+
 def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
     """hipcc cross-compiles the gfx950 code objects without a GPU: fsmc_capi.hip (host side + kernel selection),
     fsmc_identify_sort.hip and fsmc_identify_seeds.hip (rocPRIM sorts of the identification step) and fsmc_inst.hip once per family member, in parallel, linked into one shared library."""
     srcs = hip_sources()
-    if not force and _newer(HIP_LIB, srcs):
-        return HIP_LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
-    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c"]
+    stamp = os.path.join(OBJ_DIR, "members.txt")  # (another list of exact members is another library)
+    members = " ".join(str(k) for k in KT_MEMBERS + EXACT_MEMBERS + W2_MEMBERS)
+    if not force and _newer(HIP_LIB, srcs) and os.path.exists(stamp) and open(stamp).read() == members:
+        return HIP_LIB
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + exact_define() + ["-c"]
     if verbose:
         cflags.append("-Rpass-analysis=kernel-resource-usage")
     units = [("capi", os.path.join(CSRC, "fsmc_capi.hip"), []),
              ("idsort", os.path.join(CSRC, "fsmc_identify_sort.hip"), []),
              ("idseeds", os.path.join(CSRC, "fsmc_identify_seeds.hip"), [])]
-    units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"]) for k in KT_MEMBERS]
+    units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"])
+              for k in KT_MEMBERS + EXACT_MEMBERS]
     units += [(f"w2_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_W2={k}"]) for k in W2_MEMBERS]
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
     pending = list(units)
@@ -82,6 +99,7 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objs], check=True, cwd=ROOT)
+    open(stamp, "w").write(members)
     return HIP_LIB
 
 

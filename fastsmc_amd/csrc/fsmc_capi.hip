@@ -244,11 +244,12 @@ std::vector<float> padRows(const float* src, size_t rows, int K, int KP)
 using KernelFn = void (*)(const KParams);
 
 // Which member of the lane-per-pair family decodes a model (fsmc_instances.h): 69 for the reference's 69-state
-// models, the padded row length for every other model of at most 128 states, 0 (runtime K) beyond.
+// models and K itself where the library has an exact member of K states, the padded row length for every other model
+// of at most 128 states, 0 beyond.
 int familyMember(const fsmc_model* m)
 {
-  if (m->K == 69) {
-    return 69;
+  if (exactMember(m->K)) {
+    return m->K;
   }
   return (m->K <= 128 && m->KP % kKPad == 0 && m->KP <= 128) ? m->KP : 0;
 }
@@ -387,24 +388,12 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
   const int member = familyMember(m);
   m->ctx->lastMember = member;
   switch (member) {
-  case 16:
-    return pickMember<16>(mode, track, m->sequence, half, dual);
-  case 32:
-    return pickMember<32>(mode, track, m->sequence, half, dual);
-  case 48:
-    return pickMember<48>(mode, track, m->sequence, half, dual);
-  case 64:
-    return pickMember<64>(mode, track, m->sequence, half, dual);
-  case 69:
-    return pickMember<69>(mode, track, m->sequence, half, dual);
-  case 80:
-    return pickMember<80>(mode, track, m->sequence, half, dual);
-  case 96:
-    return pickMember<96>(mode, track, m->sequence, half, dual);
-  case 112:
-    return pickMember<112>(mode, track, m->sequence, half, dual);
-  case 128:
-    return pickMember<128>(mode, track, m->sequence, half, dual);
+#define FSMC_PICK_CASE(KTX)                                                                                             \
+  case KTX:                                                                                                            \
+    return pickMember<KTX>(mode, track, m->sequence, half, dual);
+    FSMC_ALL_KT(FSMC_PICK_CASE)
+    FSMC_EXACT_KT(FSMC_PICK_CASE)
+#undef FSMC_PICK_CASE
   default:
     return nullptr; // (no such model passes fsmc_model_create: K <= 128 has a member, 128 < K <= 256 the wave-group kernel)
   }

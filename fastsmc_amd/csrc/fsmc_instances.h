@@ -9,6 +9,9 @@
 //   KT = 69               the 69-state models of the reference's decoding-quantities files, no padding
 //   KT = 16, 32, 48, 64, 80   every other model with K <= 80: padded with ghost states to the next member
 //   KT = 96, 112, 128     80 < K <= 128: the same kernel with one wave per SIMD (512 registers a lane)
+//   exact members (FSMC_EXACT_KT, default 50 and 100; any K that is not a multiple of 16 may be listed at build time:
+//   `FSMC_EXACT_MEMBERS="50 100 75" python -m fastsmc_amd.build`): a model of exactly that many states runs without
+//   ghost states, masks and run-time state counts -- what the 69-state member is to the reference's own files
 // Wave-group kernel (decode_kernel_w2<KH, MODE, TRACK, SEQ>), lane = pair and four waves per group: 128 < K <= 256,
 //   KH = 48, 64 states per wave.
 // Any-K kernel (decode_kernel_any<MODE, TRACK, SEQ>, fsmc_kernels_any.h): K > 256, a pair's K-vectors in the workspace
@@ -24,10 +27,20 @@
 namespace fsmc
 {
 
+// Exact (ghost-free) members beside the 69-state one: Y(K) for every K listed (none a multiple of 16, each <= 128)
+#ifndef FSMC_EXACT_KT
+#define FSMC_EXACT_KT(Y) Y(50) Y(100)
+#endif
+#define FSMC_IS_EXACT_TERM(KTX) || KT == KTX
+constexpr bool exactMember(const int KT)
+{
+  return KT == 69 FSMC_EXACT_KT(FSMC_IS_EXACT_TERM);
+}
+
 // beta stride 2 needs three K-vectors in a lane's registers: built for the members it fits
 constexpr bool halfBuilt(const int KT)
 {
-  return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 69 || KT == 80 || KT == 96 || KT == 112 || KT == 128;
+  return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 80 || KT == 96 || KT == 112 || KT == 128 || exactMember(KT);
 }
 
 #define FSMC_KT_KERNELS(X, KT)                                                                                         \
@@ -86,6 +99,13 @@ constexpr bool halfBuilt(const int KT)
 #if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_W2)
 #define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)
 FSMC_ALL_KT(FSMC_DECLARE_MEMBER)
+#define FSMC_DECLARE_EXACT_MEMBER(KT)                                                                                   \
+  static_assert(KT % 16 != 0 && KT <= 128, "an exact member is not a multiple of 16 states and has at most 128");       \
+  FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)                                                                                  \
+  FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, KT)                                                                             \
+  FSMC_DECLARE_KT_DUAL_HALF(KT)                                                                                         \
+  FSMC_DECLARE_KT_DUAL(KT)
+FSMC_EXACT_KT(FSMC_DECLARE_EXACT_MEMBER)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 16)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 32)
 FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 48)

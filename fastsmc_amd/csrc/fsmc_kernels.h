@@ -998,7 +998,7 @@ __device__ __forceinline__ void scanBlocks(float (&w)[KA], float& s, const float
 // 112 and 128 states keep their two or three K-vectors in registers only with the whole 512-entry file (one wave).
 constexpr int minWavesPerSimd(const int KT)
 {
-  return KT >= 80 ? 1 : 2;
+  return KT >= 70 ? 1 : 2; // (the exact members between 69 and 80 states: three K-vectors no longer fit 256 registers)
 }
 //
 // DUAL: two half-groups per wavefront (hashing mode: a batch is 32 pairs, half a wave).  Lanes 0..31 decode half A, lanes

@@ -26,8 +26,8 @@ def _member(K, consumer="ibd"):
     """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; up to 448 the four-waves-per-group
     kernel (1000 + states per wave: 48 / 64 with two workgroups per CU, 80 / 96 / 112 with one); beyond, 0 = the any-K
     kernel (a pair's K-vectors in the workspace)."""
-    if K == 69:
-        return 69
+    if K in (69, 50, 100):  # the exact members of the default build (fsmc_instances.h: FSMC_EXACT_KT)
+        return K
     if K <= 128:
         return (K + 15) // 16 * 16
     if K > 448:
@@ -39,7 +39,7 @@ def _stride(K):
     return 2 if K <= 128 else 1  # every member of the lane-per-pair family is built with beta stride 2
 
 
-@pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 50, 64, 65, 70, 80, 81, 100, 128, 130, 192, 200, 256, 257, 300, 320, 321,
+@pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 49, 50, 51, 64, 65, 70, 80, 81, 99, 100, 101, 128, 130, 192, 200, 256, 257, 300, 320, 321,
                                402, 448, 449, 520])
 def test_generic_kernel_matches_oracle(K):
     pm, bits, folded = _problem(K)
@@ -85,9 +85,10 @@ def test_generic_kernel_matches_oracle(K):
     ctx.close()
 
 
-@pytest.mark.parametrize("K", [12, 40, 64, 100])
-def test_padded_members_stride_and_chunking(K):
-    """The padded members through the checkpoint / rebuild layout and both beta strides: same records as the oracle."""
+@pytest.mark.parametrize("K", [12, 40, 50, 64, 100, 105])
+def test_padded_and_exact_members_stride_and_chunking(K):
+    """The padded members (and the exact ones: 50, 100) through the checkpoint / rebuild layout and both beta strides:
+    same records as the oracle."""
     pm, bits, folded = _problem(K, S=333, seed=5)
     pairs = O.enumerate_all_pairs(32)[:70]
     pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)

@@ -26,10 +26,10 @@ def test_no_instruction_touches_a_scalar_load_in_flight(tmp_path):
     sys.path.insert(0, ROOT)
     from concurrent.futures import ThreadPoolExecutor
 
-    from fastsmc_amd.build import HIPCC_FLAGS, KT_MEMBERS, W2_MEMBERS
+    from fastsmc_amd.build import EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, W2_MEMBERS, exact_define
 
-    flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    jobs = [(ROOT, flags, f"-DFSMC_INSTANCE_KT={k}", str(tmp_path / f"kt{k}.s")) for k in KT_MEMBERS]
+    flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + exact_define()
+    jobs = [(ROOT, flags, f"-DFSMC_INSTANCE_KT={k}", str(tmp_path / f"kt{k}.s")) for k in KT_MEMBERS + EXACT_MEMBERS]
     # (the four-waves-per-group kernel uses the same operand loads; the four-lanes-per-pair kernel has none)
     jobs += [(ROOT, flags, f"-DFSMC_INSTANCE_W2={k}", str(tmp_path / f"w2_{k}.s")) for k in W2_MEMBERS]
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:

@@ -13,10 +13,10 @@ mkdir -p $OBJ
 FLAGS="-std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wno-pass-failed -c"
 PIDS=""
 hipcc $FLAGS "$@" -o $OBJ/capi.o $ROOT/fastsmc_amd/csrc/fsmc_capi.hip & PIDS="$PIDS $!"
-for K in 16 32 48 64 69 80 96 112 128; do
+for K in 16 32 48 50 64 69 80 96 100 112 128; do
   hipcc $FLAGS "$@" -DFSMC_INSTANCE_KT=$K -o $OBJ/kt$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
 done
-for K in 48 64; do
+for K in 48 64 80 96 112; do
   hipcc $FLAGS "$@" -DFSMC_INSTANCE_W2=$K -o $OBJ/w2_$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
 done
 hipcc $FLAGS -o $OBJ/idsort.o $ROOT/fastsmc_amd/csrc/fsmc_identify_sort.hip & PIDS="$PIDS $!"
