@@ -1845,23 +1845,49 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
               }
             }
             const int t0 = (h0 ? kk0 : 0) * 65, t1 = (h1 ? kk1 : 0) * 65;
-            for (int v = 0; v < nPairsInGroup; ++v) {
-              const float q0 = tile[t0 + v], q1 = tile[t1 + v];
-              s[0] = s[0] + q0;
-              s[1] = s[1] + q1;
-              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                const int cv = cls[v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
-                if (cv == 2) {
-                  s11[0] = s11[0] + q0;
-                  s11[1] = s11[1] + q1;
-                } else if (cv == 1) {
-                  s00[0] = s00[0] + q0;
-                  s00[1] = s00[1] + q1;
-                } else {
-                  s01[0] = s01[0] + q0;
-                  s01[1] = s01[1] + q1;
+            // The walk over the batch's pairs, sixteen at a time: the tile values of sixteen pairs are read together
+            // (one wait), then added one after the other -- the reference's order of additions (HMM.cpp:1054-1073).
+            // As a loop of one pair a turn (rounds 1-3) every turn waited for its own two LDS reads and took a branch:
+            // ~70 cycles a pair on a wave that runs alone.  The 00 / 01 / 11 split adds +0.f to the two sums a pair
+            // does not belong to (x + 0.f == x for the non-negative sums) instead of branching on the pair's class.
+            auto walk = [&](auto splitTag) {
+              constexpr bool SPLIT = decltype(splitTag)::value;
+              constexpr int kWalk = 16;
+              auto add = [&](const float q0, const float q1, const int cv) {
+                s[0] = s[0] + q0;
+                s[1] = s[1] + q1;
+                if constexpr (SPLIT) { // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
+                  s11[0] = s11[0] + (cv == 2 ? q0 : 0.f);
+                  s11[1] = s11[1] + (cv == 2 ? q1 : 0.f);
+                  s00[0] = s00[0] + (cv == 1 ? q0 : 0.f);
+                  s00[1] = s00[1] + (cv == 1 ? q1 : 0.f);
+                  s01[0] = s01[0] + (cv == 0 ? q0 : 0.f);
+                  s01[1] = s01[1] + (cv == 0 ? q1 : 0.f);
+                }
+              };
+              int v = 0;
+              for (; v + kWalk <= nPairsInGroup; v += kWalk) {
+                float q0[kWalk], q1[kWalk];
+                int cv[kWalk];
+#pragma unroll
+                for (int i = 0; i < kWalk; ++i) {
+                  q0[i] = tile[t0 + v + i];
+                  q1[i] = tile[t1 + v + i];
+                  cv[i] = SPLIT ? (int)cls[v + i] : 0;
+                }
+#pragma unroll
+                for (int i = 0; i < kWalk; ++i) {
+                  add(q0[i], q1[i], cv[i]);
                 }
               }
+              for (; v < nPairsInGroup; ++v) {
+                add(tile[t0 + v], tile[t1 + v], SPLIT ? (int)cls[v] : 0);
+              }
+            };
+            if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+              walk(std::true_type{});
+            } else {
+              walk(std::false_type{});
             }
             if (p.flags & FSMC_WANT_SUMS) {
               if (h0) acc0[0] = s[0];

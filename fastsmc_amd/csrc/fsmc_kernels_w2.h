@@ -1266,19 +1266,41 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
                   s11 = acc[3 * p.sumsPlane];
                 }
               }
-              for (int v = 0; v < nPairsInGroup; ++v) {
-                const float q = tile[kLocal * kWave + ((v + kLocal) & (kWave - 1))];
-                s = s + q;
-                if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                  const int cv = clsLds[h][v]; // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
-                  if (cv == 2) {
-                    s11 = s11 + q;
-                  } else if (cv == 1) {
-                    s00 = s00 + q;
-                  } else {
-                    s01 = s01 + q;
+              // (sixteen pairs a turn: their tile values are read together, then added in batch order; the 00 / 01 /
+              //  11 split adds +0.f to the sums a pair does not belong to -- fsmc_kernels.h, same place)
+              auto walk = [&](auto splitTag) {
+                constexpr bool SPLIT = decltype(splitTag)::value;
+                constexpr int kWalk = 16;
+                auto add = [&](const float q, const int cv) {
+                  s = s + q;
+                  if constexpr (SPLIT) { // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
+                    s11 = s11 + (cv == 2 ? q : 0.f);
+                    s00 = s00 + (cv == 1 ? q : 0.f);
+                    s01 = s01 + (cv == 0 ? q : 0.f);
+                  }
+                };
+                int v = 0;
+                for (; v + kWalk <= nPairsInGroup; v += kWalk) {
+                  float q[kWalk];
+                  int cv[kWalk];
+#pragma unroll
+                  for (int i = 0; i < kWalk; ++i) {
+                    q[i] = tile[kLocal * kWave + ((v + i + kLocal) & (kWave - 1))];
+                    cv[i] = SPLIT ? (int)clsLds[h][v + i] : 0;
+                  }
+#pragma unroll
+                  for (int i = 0; i < kWalk; ++i) {
+                    add(q[i], cv[i]);
                   }
                 }
+                for (; v < nPairsInGroup; ++v) {
+                  add(tile[kLocal * kWave + ((v + kLocal) & (kWave - 1))], SPLIT ? (int)clsLds[h][v] : 0);
+                }
+              };
+              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                walk(std::true_type{});
+              } else {
+                walk(std::false_type{});
               }
               if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
               if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
