@@ -783,11 +783,14 @@ template <int KT> __device__ __forceinline__ cfloat_p rowSetOf(const Tables& t, 
 // spill operand blocks right behind their loads in SOME instantiations).  The in-flight check of every compiled
 // member (tools/check_inflight_sgprs.py, tests/test_isa_hazards.py) shows which: the 16- and 32-state members; all the
 // others -- among them the 69-state member of the reference's own files -- are clean with the asynchronous loads of
-// array mode, one operand block ahead, and use them.  (-DFSMC_SEQ_SYNC_LOADS: synchronous everywhere, as before.)
+// array mode, one operand block ahead, and use them -- in the IBD decode, the product's path; the three other consumers
+// of sequence mode (posterior dump, per-pair rows, sums over pairs) keep the synchronous loads: which of their
+// instantiations are clean moved with an unrelated change to the sums consumer (64-state member), and they are not
+// worth a list of their own.  (-DFSMC_SEQ_SYNC_LOADS: synchronous everywhere, as before.)
 #if defined(FSMC_SEQ_SYNC_LOADS)
-template <bool SEQ, int KT> constexpr bool kSeqSyncLoads = SEQ;
+template <bool SEQ, int KT, int MODE> constexpr bool kSeqSyncLoads = SEQ;
 #else
-template <bool SEQ, int KT> constexpr bool kSeqSyncLoads = SEQ && KT <= 32;
+template <bool SEQ, int KT, int MODE> constexpr bool kSeqSyncLoads = SEQ && (KT <= 32 || MODE != kModeIbd);
 #endif
 template <int KT, int KA, bool SCALE = true, bool SY = false>
 __device__ __forceinline__ void beta_step(const int K, float (&b)[KA], float (&w)[KA], const Tables& t, const int row,
@@ -1269,7 +1272,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
     auto betaGapStep = [&](float (&b)[KA], const int q, const EmisRegs& rows) {
       commitEmis(q, rows);
       const int row = tRowGapB[q];
-      beta_step<KT, KA, false, kSeqSyncLoads<SEQ, KT>>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW);
+      beta_step<KT, KA, false, kSeqSyncLoads<SEQ, KT, MODE>>(K, b, w, tabs, row, &emisLds[q & 1][3 * E4], cycW);
     };
     auto betaSeqStep = [&](float (&b)[KA], const int pos) {
       const int q = pos + 1;
@@ -1280,7 +1283,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
       }
       const int c = obsClass(q);
       const int row = tRowSiteB[q];
-      beta_step<KT, KA, true, kSeqSyncLoads<SEQ, KT>>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+      beta_step<KT, KA, true, kSeqSyncLoads<SEQ, KT, MODE>>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
       if (gap) {
         betaGapStep(b, pos, ev);
       }
@@ -1400,7 +1403,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
             }
             const int row = stepRowOf(q);
             const int c = obsClass(q);
-            beta_step<KT, KA, true, kSeqSyncLoads<SEQ, KT>>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+            beta_step<KT, KA, true, kSeqSyncLoads<SEQ, KT, MODE>>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
             afterBeta(pos);
           }
         }
@@ -1578,7 +1581,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
               }
               const int row = stepRowOf(q);
               const int c = obsClass(q);
-              beta_step<KT, KA, true, kSeqSyncLoads<SEQ, KT>>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
+              beta_step<KT, KA, true, kSeqSyncLoads<SEQ, KT, MODE>>(K, b, w, tabs, row, &emisLds[q & 1][c * E4], cycW);
               storeRow(pos, b);
             }
           }
@@ -1626,7 +1629,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
         if (__builtin_expect(pos == from, 0)) {
           alpha_init<KT, KA>(K, a, tPi, e);
         } else {
-          alpha_step<KT, KA, true, kSeqSyncLoads<SEQ, KT>>(K, a, w, tabs, stepRowOf(pos), e, cycW);
+          alpha_step<KT, KA, true, kSeqSyncLoads<SEQ, KT, MODE>>(K, a, w, tabs, stepRowOf(pos), e, cycW);
           if constexpr (DUAL) {
             // the lanes whose own window opens here start from pi * emission (HMM.cpp:736-747)
             if (pos == fromA || pos == fromB) {
@@ -1645,7 +1648,7 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
           if (pos < to - 1) {
             commitEmis(pos + 1, ev);
             const int row = tRowGapF[pos + 1];
-            alpha_step<KT, KA, false, kSeqSyncLoads<SEQ, KT>>(K, a, w, tabs, row, &emisLds[(pos + 1) & 1][3 * E4],
+            alpha_step<KT, KA, false, kSeqSyncLoads<SEQ, KT, MODE>>(K, a, w, tabs, row, &emisLds[(pos + 1) & 1][3 * E4],
                                             cycW);
           }
         }
