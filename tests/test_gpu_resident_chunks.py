@@ -91,3 +91,71 @@ def test_workspace_is_earned_without_a_limit(small_problem, monkeypatch):
     free, _ = run(1)
     assert free[0][0] == chunks                                   # a problem this small fits the free allowance
     assert len({b for _, b in poor + rich + free}) == 1           # the records do not depend on the plan
+
+
+def _groups_and_pairs():
+    n = WINS[-1][0] + WINS[-1][1]
+    pairs = O.enumerate_all_pairs(32)[500:500 + n]
+    groups = np.zeros(len(WINS), capi.GROUP_DTYPE)
+    for g, w in zip(groups, WINS):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    return pairs, groups
+
+
+def test_an_announced_job_has_its_workspace_at_the_first_launch(small_problem, monkeypatch):
+    """fsmc_ctx_expect_work (what HMM::decodeAll knows when it starts, HMM.cpp:310-321): under the library's own policy
+    the credit of the whole announced job is there at the first launch -- here a job announced big enough pays for
+    every chunk's rows at once, with the free allowance switched off -- and the records do not depend on it."""
+    pairs, groups = _groups_and_pairs()
+    flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
+    monkeypatch.setenv("FSMC_DIAG_WS_FREE", "1")
+    out = {}
+    for announce in (0.0, 1e15):
+        ctx, model = _ctx(small_problem, 2, limit=0, chunk=48)
+        if announce:
+            ctx.expect_work(announce, small_problem["model"].K)
+        rec = ctx.decode_ibd(model, _pairs_array(pairs), groups, flags)
+        out[announce] = (ctx.last_resident_chunks(), ctx.info()["max_chunks"], rec.tobytes())
+        ctx.close()
+    assert out[0.0][0] == 0 and out[1e15][0] == out[1e15][1] > 10
+    assert out[0.0][2] == out[1e15][2]
+    ctx, _ = _ctx(small_problem, 2, limit=0, chunk=48)
+    with pytest.raises(capi.FsmcError):
+        ctx.expect_work(-1.0, 69)
+    ctx.close()
+
+
+def test_workspace_growth_is_amortised(small_problem, monkeypatch):
+    """A bigger workspace is a new allocation of its whole size (hipMalloc: ~40 ms per GB), so the plan is upgraded only
+    when the credit covers TWICE the buffer held, and an allocation is debited from the credit: with launches that each
+    earn a third of the first plan's buffer the number of resident chunks does not creep up launch by launch (what it
+    did until round 4: a re-allocation at almost every flush of a long job) -- it stays put for several launches and
+    then moves in a few large steps."""
+    pm = small_problem["model"]
+    pairs, groups = _groups_and_pairs()
+    flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
+    monkeypatch.setenv("FSMC_DIAG_WS_FREE", "1")
+    # the buffer of the plan without upgrades: (chunk rows + checkpoints + 4 side rows) of K/4 x 64 float4 per slot
+    ctx, model = _ctx(small_problem, 2, limit=0, chunk=48)
+    ctx.decode_ibd(model, _pairs_array(pairs), groups, flags)
+    info = ctx.info()
+    assert ctx.last_resident_chunks() == 0
+    ctx.close()
+    k4 = (pm.K + 3) // 4
+    slots = min(len(WINS), info["n_slots"])
+    base_bytes = (48 // 2 + info["max_chunks"] + 4) * k4 * 64 * 16 * slots
+    pair_sites = float(sum(w[1] * (w[5] - w[2]) for w in WINS))
+    seconds = pair_sites * (8 * pm.K + 0.25) / (0.8 * 8e12)
+    per_launch = base_bytes / 3.0  # what one launch is to earn
+    monkeypatch.setenv("FSMC_DIAG_WS_EARN_SCALE", repr(per_launch / (0.06 * seconds * 25e9)))
+    ctx, model = _ctx(small_problem, 2, limit=0, chunk=48)
+    resident, recs = [], set()
+    for _ in range(24):
+        recs.add(ctx.decode_ibd(model, _pairs_array(pairs), groups, flags).tobytes())
+        resident.append(ctx.last_resident_chunks())
+    ctx.close()
+    assert len(recs) == 1
+    assert resident == sorted(resident) and resident[-1] > 0          # it does grow ...
+    assert resident[:4] == [0, 0, 0, 0]                                  # ... not before the credit covers 2 x the buffer
+    steps = sum(1 for a, b in zip(resident, resident[1:]) if b != a)
+    assert steps <= 4, resident                                          # ... and in a few steps, not one per launch
