@@ -598,7 +598,9 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   size_t resident = 0;
   if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && !anyStates(m) && ctx->residentChunks != 0) {
     const size_t rowsBudget = rowsSoft;
-    const size_t fixed = chunkRows(C) + maxChunks + sideRows + 1;
+    // (exactly the rows of plan.wsSlot below: a plan must qualify again for the buffer it was given -- with a row of
+    //  slack here a context whose soft budget is the buffer it holds lost one resident chunk at its next launch)
+    const size_t fixed = chunkRows(C) + maxChunks + sideRows;
     if (rowsBudget > fixed) {
       resident = std::min<size_t>((rowsBudget - fixed) / chunkRows(C), maxChunks);
       if (ctx->residentChunks > 0) {
