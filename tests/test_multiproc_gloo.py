@@ -202,3 +202,34 @@ def test_hmm_record_gather_world_size_3_with_an_empty_rank(tmp_path):
     # one process: the records as they are
     total, alone = gather_hmm_records(_FakeHmm(_fake_rows(5, 1)))
     assert total == 5 and np.array_equal(alone, _fake_rows(5, 1))
+
+
+def test_bench_start_up_of_two_ranks_builds_the_cohort_once(tmp_path):
+    """bench.py at N = 2 (the driver's launch line, gloo instead of RCCL, `--startup-only`: everything up to the first
+    GPU call): local rank 0 synthesises and prepares the cohort and leaves it in the node's cache, rank 1 maps it; the
+    host threads of a rank are capped at cores / ranks; both ranks end up with their shard of the one work list."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, FSMC_BENCH_CACHE=str(tmp_path / "cache"))
+    env.pop("FSMC_HOST_THREADS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--workload", "c3", "--haps", "64", "--sites", "700", "--pairs", "1500", "--startup-only"]
+    lines = []
+    for _ in range(2):  # the second run finds the cache file
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    files = os.listdir(tmp_path / "cache")
+    assert len(files) == 1 and files[0].startswith("cohort_") and files[0].endswith(".npz")
+    for line in lines:
+        assert line["startup_only"] and line["n_ranks"] == 2 and len(line["startup_s_per_rank"]) == 2
+        assert 0 < line["pairs_of_rank_0"] < 1500  # its shard of the one list
+        cores = len(os.sched_getaffinity(0))
+        assert line["host_threads_per_rank"] == str(max(1, cores // 2))
