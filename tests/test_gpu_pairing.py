@@ -79,8 +79,8 @@ def test_paired_half_groups_match_the_unpaired_run_and_the_oracle(small_problem,
         np.testing.assert_array_equal(paired[f_got], want[f_want], err_msg=f_got)
 
 
-@pytest.mark.parametrize("K", [12, 100])
-def test_pairing_in_the_padded_members(K):
+@pytest.mark.parametrize("K", [12, 50, 100, 105])
+def test_pairing_in_the_padded_and_exact_members(K):
     tables = synth.make_model_tables(K)
     haps = synth.make_haps(64, 500, seed=9, cm_per_mb=25.0, switch_per_cm=0.6)
     bits, derived, flipped = synth.fold_and_pack(haps.alleles)
