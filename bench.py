@@ -169,6 +169,13 @@ def all_pairs(n_ind: int) -> np.ndarray:
     return np.concatenate(out).astype(np.uint32)
 
 
+def folded_rows_from_bits(bits: np.ndarray, rows, n_sites: int) -> np.ndarray:
+    """Folded alleles [len(rows)][n_sites] uint8 of the given haplotype rows, unpacked from the packed matrix the GPU
+    decodes from ([hap][ceil(S/64)] little-endian u64, site s at bit s % 64)."""
+    words = np.ascontiguousarray(np.asarray(bits)[np.asarray(rows)]).view(np.uint8)
+    return np.unpackbits(words, axis=1, bitorder="little")[:, :n_sites]
+
+
 def cpu_baseline(pm, bits: np.ndarray, n_pairs_sample: int, pairs: np.ndarray) -> dict:
     """The oracle (C restatement of the reference's NO_SSE path; here its -O3 -mavx2 build, which tests check is
     bit-identical to the checker build) on the first pairs of the same work list, same sites, reference batch size
@@ -187,8 +194,7 @@ def cpu_baseline(pm, bits: np.ndarray, n_pairs_sample: int, pairs: np.ndarray) -
         n_pairs_sample = 4 * 32 * cores
     sample_pairs = np.asarray(pairs[:n_pairs_sample], dtype=np.int64)
     used, inverse = np.unique(sample_pairs, return_inverse=True)
-    words = np.ascontiguousarray(bits[used]).view(np.uint8)  # (little-endian words: site s is bit s % 8 of byte s / 8)
-    folded = np.unpackbits(words, axis=1, bitorder="little")[:, : pm.S]
+    folded = folded_rows_from_bits(bits, used, pm.S)
     sample = [tuple(int(x) for x in pr) for pr in inverse.reshape(sample_pairs.shape)]
     O.select_build("avx2")
     try:

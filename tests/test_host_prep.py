@@ -225,3 +225,19 @@ def test_expected_coal_times_file_is_read_like_the_reference(tmp_path):
     p.FastSMC = True
     p.expectedCoalTimesFile = bad
     api.HMM(data, dq, p)  # FastSMC mode does not look at it
+
+
+def test_bench_unpacks_the_folded_alleles_it_gives_the_cpu_baseline():
+    """bench.py's cpu_baseline decodes the first pairs of the GPU's own work list on the host: the folded alleles it
+    hands the oracle come out of the packed matrix the GPU decodes from (`folded_rows_from_bits`) -- they must be the
+    folded alleles of the cohort, whatever the number of sites modulo 64."""
+    import numpy as np
+    import bench
+    from fastsmc_amd import synth
+
+    for n_sites in (64, 100, 129):
+        pm, bits, haps, _ = bench.build_problem(64, n_sites, 12, seed=5)
+        _, _, flipped = synth.fold_and_pack(haps.alleles)
+        folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+        rows = np.array([0, 3, 17, 63])
+        np.testing.assert_array_equal(bench.folded_rows_from_bits(bits, rows, n_sites), folded[rows])
