@@ -82,6 +82,10 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"])
               for k in KT_MEMBERS + EXACT_MEMBERS]
     units += [(f"w2_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_W2={k}"]) for k in W2_MEMBERS]
+    # longest first (the wide members take a minute or more each, the small ones seconds): the queue's tail is short
+    cost = lambda u: (int(u[0].split("_")[1]) + 1000 if u[0].startswith("w2_") else int(u[0][2:]) if u[0][2:].isdigit()
+                      else 60)  # noqa: E731
+    units.sort(key=cost, reverse=True)
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
     pending = list(units)
     running: list[tuple[str, subprocess.Popen]] = []
