@@ -12,7 +12,7 @@ OUT=$ROOT/fastsmc_amd/variants
 OBJ=$OUT/obj_$NAME
 mkdir -p $OBJ
 FLAGS="-std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wno-pass-failed"
-SRC=$ROOT/fastsmc_amd/csrc/fsmc_inst.hip
+SRC=${FSMC_SRC_DIR:-$ROOT/fastsmc_amd/csrc}/fsmc_inst.hip  # (FSMC_SRC_DIR: an edited COPY of csrc/ for diagnostic builds -- the library's own sources, hence its hash, stay as they are)
 PIDS=""
 for K in 48 64; do
   hipcc $FLAGS "$@" -c -DFSMC_INSTANCE_W2=$K -Rpass-analysis=kernel-resource-usage -o $OBJ/w2_$K.o $SRC 2> $OBJ/w2_$K.res & PIDS="$PIDS $!"
@@ -42,7 +42,7 @@ for b in blocks[1:]:
     print("w2<64, ibd, track>:", "VGPRs", f("VGPRs"), "AGPRs", f("AGPRs"), "spill VGPR", f("VGPRs Spill"), "spill SGPR", f("SGPRs Spill"),
           "scratch", f("ScratchSize \[bytes/lane\]"), "LDS", f("LDS Size \[bytes/block\]"), "occupancy", f("Occupancy \[waves/SIMD\]"))
 PY
-OBJS=$(ls $ROOT/fastsmc_amd/csrc/obj/*.o | grep -v "/w2_")
+OBJS=$(ls $ROOT/fastsmc_amd/csrc/obj/*.o | grep -v "/w2_48.o\|/w2_64.o")  # (the 80 ... 112-state members are the shipped build's)
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib$NAME.so $OBJS $OBJ/w2_48.o $OBJ/w2_64.o
 rm -rf $OBJ
 echo "built $OUT/lib$NAME.so"
