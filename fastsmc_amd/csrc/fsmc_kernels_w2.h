@@ -275,13 +275,27 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         T[i] = t.x;
         T[i + 1] = t.y;
       }
+      // the recurrence (two dependent operations a state), then -- second pass of a lower-half wave -- the block's BU
+      // added to what the ascending pass left in w, two states an instruction (as a plain add a state inside the chain
+      // loop it was 64 instructions of the 287 on this pass's way, and this pass is the longer one of its phase)
+      float BUb[BS];
 #pragma unroll
       for (int i = BS - 1; i >= 0; --i) {
-        const int k = blk * BS + i;
         const float tNext = (i == BS - 1) ? tAbove : T[i + 1];
         const float bu = tNext + rr[i] * buAbove;
         buAbove = bu;
-        w[k] = accumulate ? w[k] + bu : bu;
+        BUb[i] = bu;
+      }
+#pragma unroll
+      for (int i = 0; i < BS; i += 2) {
+        const int k = blk * BS + i;
+        f32x2 x = {BUb[i], BUb[i + 1]};
+        if (accumulate) {
+          const f32x2 wv = {w[k], w[k + 1]};
+          x = padd(wv, x);
+        }
+        w[k] = x.x;
+        w[k + 1] = x.y;
       }
       tAbove = T[0];
     }
@@ -462,17 +476,15 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
   // wave 0 in phase 0 (AU[0] = 0; the B term follows in phase 1), wave 1 in phase 1 from wave 0's AU of state KH with
   // its suffix sums (w[k] = alphaC[k+1]) at hand: w[k] = e[k]*term
   auto ascending = [&](const float auIn, const bool complete) {
-    SVec d, u, c4, bt, nd, nu, nc, nbt;
+    SVec d, u, c4, nd, nu, nc;
     EmisBlk<kWBF> em, nem;
     d = LD<kWBF, false>::loadAt(rsw, kRowD * KP);
     u = LD<kWBF, false>::loadAt(rsw, kRowU * KP);
     c4 = LD<kWBF, false>::loadAt(crw, 0);
-    Touched td, tu, tb;
+    Touched td, tu;
     touchRow<1, kLines - 1>(td, rsw, kRowD * KP);
     touchRow<1, kLines - 1>(tu, rsw, kRowU * KP);
     if (complete) {
-      bt = LD<kWBF, false>::loadAt(rsw, kRowB * KP);
-      touchRow<1, kLines - 1>(tb, rsw, kRowB * KP);
       em = readEmis<kWBF>(e, 0);
     }
     float AU = auIn;
@@ -480,25 +492,17 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     for (int blk = 0; blk < NBF; ++blk) {
       FSMC_WAIT_OPERANDS(dummy);
       if (blk > 0) {
-        if (complete) {
-          landed(nd, nu, nc, nbt);
-          bt = nbt;
-          em = nem;
-        } else {
-          landed(nd, nu);
-          landed(nc);
-        }
+        landed(nd, nu);
+        landed(nc);
         d = nd;
         u = nu;
         c4 = nc;
-      } else {
         if (complete) {
-          landed(d, u, c4, bt);
-          heldRow<kLines - 1>(tb);
-        } else {
-          landed(d, u);
-          landed(c4);
+          em = nem;
         }
+      } else {
+        landed(d, u);
+        landed(c4);
         heldRow<kLines - 1>(td);
         heldRow<kLines - 1>(tu);
       }
@@ -507,7 +511,6 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
         nu = LD<kWBF, false>::loadAt(rsw, kRowU * KP + (blk + 1) * kWBF);
         nc = LD<kWBF, false>::loadAt(crw, (blk + 1) * kWBF);
         if (complete) {
-          nbt = LD<kWBF, false>::loadAt(rsw, kRowB * KP + (blk + 1) * kWBF);
           nem = readEmis<kWBF>(e, blk + 1);
         }
       }
@@ -523,8 +526,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
         au.y = ua.x + c4[i] * AU; // AU of state k+1
         f32x2 term = padd(au, da);
         if (complete) {
-          const f32x2 ac = {w[k], w[k + 1]};
-          const f32x2 bw = pmul(pairOf(bt, i), ac);
+          // w holds B[k] * alphaC[k+1] (the suffix pass formed the product on its way down)
+          const f32x2 bw = {w[k], w[k + 1]};
           term = padd(term, bw);
           term = pmul(em.pair(i), term);
         }
@@ -538,14 +541,44 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     }
   };
   // ---- suffix sums, descending: alphaC[k] = alphaC[k+1] + alpha[k] (HMM.cpp:799-814)
-  // upper half: operand-free, w[k] = alphaC of the state above k (what the B term of state k needs); the model's last
-  // state has no state above it: its slot is 0 and B*0 leaves its term unchanged (HMM.cpp:823-826)
+  // upper half: w[k] = B[k] * alphaC of the state above k (what the term of state k adds, HMM.cpp:823-826: the product is
+  // formed here, on the way down, in the phase the lower half's longer pass sets the pace of -- the upper half's
+  // ascending pass, the longest of the step, is that much shorter); the model's last state has no state above it: its
+  // alphaC is 0 and B*0 = +0 leaves its term unchanged
   auto suffix = [&](const float cIn) {
+    SVec bt, nbt;
+    bt = LD<kWBF, false>::loadAt(rsw, kRowB * KP + (NBF - 1) * kWBF);
+    Touched tb;
+    touchRow<0, kLines - 1>(tb, rsw, kRowB * KP);
     float c = cIn;
 #pragma unroll
-    for (int k = KH - 1; k >= 0; --k) {
-      w[k] = c;
-      c = c + a[k];
+    for (int blk = NBF - 1; blk >= 0; --blk) {
+      FSMC_WAIT_OPERANDS(dummy);
+      if (blk == NBF - 1) {
+        landed(bt);
+        heldRow<kLines - 1>(tb);
+      } else {
+        landed(nbt);
+        bt = nbt;
+      }
+      if (blk > 0) {
+        nbt = LD<kWBF, false>::loadAt(rsw, kRowB * KP + (blk - 1) * kWBF);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float ac[kWBF];
+#pragma unroll
+      for (int i = kWBF - 1; i >= 0; --i) {
+        ac[i] = c;
+        c = c + a[blk * kWBF + i];
+      }
+#pragma unroll
+      for (int i = 0; i < kWBF; i += 2) {
+        const int k = blk * kWBF + i;
+        const f32x2 acv = {ac[i], ac[i + 1]};
+        const f32x2 bw = pmul(pairOf(bt, i), acv);
+        w[k] = bw.x;
+        w[k + 1] = bw.y;
+      }
     }
     cx.mail[(kW2RowC + H - 1) * kWave + cx.lane] = c; // alphaC of this wave's first state (H >= 2 here)
   };
@@ -632,11 +665,11 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
       }
 #endif
     }
-    // idle-phase warm-up (WarmRows): wave 1 reads D, U in phase 1 and B in phase 2, wave 2 D, U, B in phase 2 -- both sit
-    // out phase 0; wave 0 reads B and wave 3 D, U, B in phase 3 -- both sit out phase 1 (the column ratios are one row for
-    // every step: always cached)
+    // idle-phase warm-up (WarmRows): wave 1 reads D, U in phase 1 and B in phase 2, wave 2 B in phase 1 and D, U in phase
+    // 2 -- both sit out phase 0; wave 0 reads B and wave 3 D, U in phase 3 -- both sit out phase 1 (the column ratios are
+    // one row for every step: always cached)
     WarmRows<KH, KP, kRowD, kRowU, kRowB> warmInner;
-    WarmRows<KH, KP, kRowB, (H == 0 ? -1 : kRowD), (H == 0 ? -1 : kRowU)> warmOuter;
+    WarmRows<KH, KP, (H == 0 ? kRowB : kRowD), (H == 0 ? -1 : kRowU)> warmOuter;
     constexpr bool outerA = H == 0 || H == kW2NW - 1;
     if (!outerA && ph == 0) {
       warmInner.request(rsw);
