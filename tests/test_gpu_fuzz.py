@@ -13,10 +13,26 @@ FIELDS = (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob")
           ("map", "map"))
 
 
+def _other_model(small_problem, K, time):
+    """The small problem's haplotypes with a synthetic model of K states (another member of the kernel family)."""
+    from fastsmc_amd import synth
+
+    sp = small_problem
+    _, derived, _ = synth.fold_and_pack(sp["haps"].alleles)
+    return O.prepare_model(synth.make_model_tables(K), sp["gen"], sp["haps"].bp, derived, 64, time=time)
+
+
+# (K, time threshold): the 69-state exact member; the exact 50- and 100-state members; a padded member; the wave-group
+# kernel with two workgroups per CU (200 states, a threshold that reaches its second wave) and with one (300 states: 80 a
+# wave; 402: 112 a wave, a threshold beyond 256 states); the any-K kernel
+MODELS = [(69, 50), (50, 50), (100, 200), (105, 200), (200, 20000), (300, 200), (402, 30000), (460, 200)]
+
+
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_worklists(small_problem, seed):
     rng = np.random.default_rng(1000 + seed)
-    pm = small_problem["model"]
+    K, time = MODELS[seed % len(MODELS)] if seed >= 2 else MODELS[0]
+    pm = small_problem["model"] if K == 69 else _other_model(small_problem, K, time)
     folded = small_problem["folded"]
     S = pm.S
     allp = O.enumerate_all_pairs(32)
@@ -41,7 +57,7 @@ def test_random_worklists(small_problem, seed):
     ctx = capi.Context(0)
     ctx.set_beta_stride(int(rng.choice([0, 1, 2])))
     if rng.integers(0, 2):
-        ctx.set_workspace_limit(int(rng.choice([12, 24, 64])) << 20)
+        ctx.set_workspace_limit((int(rng.choice([12, 24, 64])) << 20) * max(1, (pm.K + 63) // 64))
         ctx.set_chunk_sites(int(rng.choice([0, 16, 32, 80])))
     model = ctx.create_model(pm)
     ctx.upload_haps(small_problem["bits"], S)
