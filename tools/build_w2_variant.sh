@@ -18,6 +18,12 @@ for K in 48 64; do
   hipcc $FLAGS "$@" -c -DFSMC_INSTANCE_W2=$K -Rpass-analysis=kernel-resource-usage -o $OBJ/w2_$K.o $SRC 2> $OBJ/w2_$K.res & PIDS="$PIDS $!"
   hipcc $FLAGS "$@" -DFSMC_INSTANCE_W2=$K -S --cuda-device-only -Wno-unused-command-line-argument -o $OBJ/w2_$K.s $SRC 2>/dev/null & PIDS="$PIDS $!"
 done
+# FSMC_VARIANT_CAPI=1: the variant changes the host side of the launch as well -- fsmc_capi.hip of FSMC_SRC_DIR is compiled too
+CAPI=$ROOT/fastsmc_amd/csrc/obj/capi.o
+if [ "${FSMC_VARIANT_CAPI:-0}" = "1" ]; then
+  CAPI=$OBJ/capi.o
+  hipcc $FLAGS "$@" -c -o $CAPI $(dirname $SRC)/fsmc_capi.hip & PIDS="$PIDS $!"  # (default exact members)
+fi
 for P in $PIDS; do wait $P; done
 for K in 48 64; do
   python3 - "$OBJ/w2_$K.s" <<'PY'
@@ -42,7 +48,7 @@ for b in blocks[1:]:
     print("w2<64, ibd, track>:", "VGPRs", f("VGPRs"), "AGPRs", f("AGPRs"), "spill VGPR", f("VGPRs Spill"), "spill SGPR", f("SGPRs Spill"),
           "scratch", f("ScratchSize \[bytes/lane\]"), "LDS", f("LDS Size \[bytes/block\]"), "occupancy", f("Occupancy \[waves/SIMD\]"))
 PY
-OBJS=$(ls $ROOT/fastsmc_amd/csrc/obj/*.o | grep -v "/w2_48.o\|/w2_64.o")  # (the 80 ... 112-state members are the shipped build's)
+OBJS="$(ls $ROOT/fastsmc_amd/csrc/obj/*.o | grep -v "/w2_48.o\|/w2_64.o\|/capi.o") $CAPI"  # (the 80 ... 112-state members are the shipped build's)
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib$NAME.so $OBJS $OBJ/w2_48.o $OBJ/w2_64.o
 rm -rf $OBJ
 echo "built $OUT/lib$NAME.so"
