@@ -23,7 +23,12 @@ KT_MEMBERS = [16, 32, 48, 64, 69, 80, 96, 112, 128]
 # states pays for no padding.  FSMC_EXACT_MEMBERS="50 100 75" in the environment of a build lists others (none a multiple
 # of 16, each <= 128 states); the list is part of the library's source hash.
 EXACT_MEMBERS = [int(x) for x in os.environ.get("FSMC_EXACT_MEMBERS", "50 100").split()]
-W2_MEMBERS = [48, 64, 80, 96, 112]
+# wave-group kernel: (states per wave, waves per group) -- csrc/fsmc_instances.h, FSMC_ALL_W2
+W2_MEMBERS = [(48, 4), (64, 4), (80, 4), (64, 6), (64, 7), (64, 8)]
+
+
+def w2_unit_name(kh: int, nw: int) -> str:
+    return f"w2_{kh}" if nw == 4 else f"w2_{kh}x{nw}"
 OBJ_DIR = os.path.join(CSRC, "obj")
 
 
@@ -70,7 +75,7 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     srcs = hip_sources()
     os.makedirs(OBJ_DIR, exist_ok=True)
     stamp = os.path.join(OBJ_DIR, "members.txt")  # (another list of exact members is another library)
-    members = " ".join(str(k) for k in KT_MEMBERS + EXACT_MEMBERS + W2_MEMBERS)
+    members = " ".join(str(k) for k in KT_MEMBERS + EXACT_MEMBERS + [w2_unit_name(*m) for m in W2_MEMBERS])
     if not force and _newer(HIP_LIB, srcs) and os.path.exists(stamp) and open(stamp).read() == members:
         return HIP_LIB
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + exact_define() + ["-c"]
@@ -81,10 +86,14 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
              ("idseeds", os.path.join(CSRC, "fsmc_identify_seeds.hip"), [])]
     units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"])
               for k in KT_MEMBERS + EXACT_MEMBERS]
-    units += [(f"w2_{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_W2={k}"]) for k in W2_MEMBERS]
+    units += [(w2_unit_name(kh, nw), os.path.join(CSRC, "fsmc_inst.hip"),
+               [f"-DFSMC_INSTANCE_W2={kh}", f"-DFSMC_INSTANCE_NW={nw}"]) for kh, nw in W2_MEMBERS]
     # longest first (the wide members take a minute or more each, the small ones seconds): the queue's tail is short
-    cost = lambda u: (int(u[0].split("_")[1]) + 1000 if u[0].startswith("w2_") else int(u[0][2:]) if u[0][2:].isdigit()
-                      else 60)  # noqa: E731
+    def cost(u):
+        if u[0].startswith("w2_"):
+            kh, _, nw = u[0][3:].partition("x")
+            return 1000 + int(kh) * int(nw or 4)
+        return int(u[0][2:]) if u[0][2:].isdigit() else 60
     units.sort(key=cost, reverse=True)
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
     pending = list(units)

@@ -95,7 +95,7 @@ struct fsmc_ctx {
   uint32_t chunkSites = 0; // 0 = automatic
   uint32_t betaStride = 0; // 0 = automatic (2 where the kernel exists), 1 = store every beta row
   int lastStride = 1;
-  int lastMember = 0; // member of the last launch: KT of the lane-per-pair kernel, 1000 + KH of the wave-group kernel
+  int lastMember = 0; // member of the last launch: KT of the lane-per-pair kernel; wave-group kernel: 1000 + KH (four waves of KH states), 1000 * NW + KH (NW = 5 ... 8 waves)
 
   // The queues an IBD decode's waves pull from (fsmc_decode_ibd_launch): built from the uploaded groups once per
   // work list and budget, longest window first.
@@ -131,6 +131,7 @@ struct fsmc_ctx {
 struct fsmc_model {
   fsmc_ctx* ctx = nullptr;
   int K = 0, KP = 0, S = 0, nRows = 0;
+  int w2NW = 0; // wave-group kernel: waves per group (each holds KP / w2NW states); 0 for every other model
   float *pi = nullptr, *cR = nullptr, *expT = nullptr;
   float *D = nullptr, *B = nullptr, *U = nullptr, *RR = nullptr;
   float* rowSets = nullptr; // [rows][5][KP]: D | B | U | Ush | RR per key, Ush[k] = U[k-1] (kernels' RowSet)
@@ -298,38 +299,54 @@ bool halfAvailable(int mode, const fsmc_model* m)
   return mode == kModeIbd && !m->sequence && halfBuilt(familyMember(m));
 }
 
-// The wide-model kernel with lane = pair and four waves per group (fsmc_kernels_w2.h): 128 < K <= 448, every consumer,
-// array and sequence mode.  fsmc_model_create pads such a model's rows to KP = 4 x the states per wave of the member:
-// 192 or 256 floats (two workgroups per CU), 320, 384 or 448 (one workgroup per CU: 80, 96, 112 states a wave).
+// The wide-model kernel with lane = pair and several waves per group (fsmc_kernels_w2.h): 128 < K <= 512, every
+// consumer, array and sequence mode.  fsmc_model_create picks the member (w2Member) and pads such a model's rows to
+// KP = waves x states per wave: four waves of 48 or 64 (two workgroups per CU) or 80 states, six to eight waves of 64.
 bool waveGroups(int mode, const fsmc_model* m)
 {
-  return familyMember(m) == 0 && m->K > 128 && m->K <= kMaxStatesW2 &&
-         (m->KP == 192 || m->KP == 256 || m->KP == 320 || m->KP == 384 || m->KP == 448) &&
-         (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair);
+  return m->w2NW > 0 && (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair);
 }
 
-template <int KH, bool SEQ> KernelFn pickWaveGroupKernelOf(int mode, bool track)
+// Member of the wave-group kernel for a model of K states: {waves per group, states per wave}.  Up to 320 states four
+// waves (48, 64: two workgroups per CU; 80: one, with the whole register file); beyond, six to eight waves of 64 states.
+// (Measured on the 600 x 3000 list, profiles/r04_wide_members_ab.txt: five waves of 64 are 6 % slower than four of 80
+// at 300 / 320 states; four waves of 96 / 112 states -- round 4's first members for 321 ... 448 states, which keep part
+// of their vectors in scratch memory -- 10 - 13 % slower than six / seven waves of 64.)
+struct W2Member {
+  int NW, KH;
+};
+W2Member w2Member(int K)
+{
+  if (K <= 192) return {4, 48};
+  if (K <= 256) return {4, 64};
+  if (K <= 320) return {4, 80};
+  if (K <= 384) return {6, 64};
+  if (K <= 448) return {7, 64};
+  return {8, 64};
+}
+
+template <int KH, int NW, bool SEQ> KernelFn pickWaveGroupKernelOf(int mode, bool track)
 {
   if (mode == kModeIbd) {
-    return track ? decode_kernel_w2<KH, kModeIbd, true, SEQ> : decode_kernel_w2<KH, kModeIbd, false, SEQ>;
+    return track ? decode_kernel_w2<KH, kModeIbd, true, SEQ, NW> : decode_kernel_w2<KH, kModeIbd, false, SEQ, NW>;
   }
   if (mode == kModeSums) {
-    return decode_kernel_w2<KH, kModeSums, false, SEQ>;
+    return decode_kernel_w2<KH, kModeSums, false, SEQ, NW>;
   }
   if (mode == kModePerPair) {
-    return decode_kernel_w2<KH, kModePerPair, false, SEQ>;
+    return decode_kernel_w2<KH, kModePerPair, false, SEQ, NW>;
   }
-  return decode_kernel_w2<KH, kModeDump, false, SEQ>;
+  return decode_kernel_w2<KH, kModeDump, false, SEQ, NW>;
 }
-template <int KH> KernelFn pickWaveGroupKernel(int mode, bool track, bool seq)
+template <int KH, int NW> KernelFn pickWaveGroupKernel(int mode, bool track, bool seq)
 {
-  return seq ? pickWaveGroupKernelOf<KH, true>(mode, track) : pickWaveGroupKernelOf<KH, false>(mode, track);
+  return seq ? pickWaveGroupKernelOf<KH, NW, true>(mode, track) : pickWaveGroupKernelOf<KH, NW, false>(mode, track);
 }
 
 // threads of a workgroup of the kernel pickKernel returns for this mode and model
 unsigned blockThreads(int mode, const fsmc_model* m)
 {
-  return waveGroups(mode, m) ? (unsigned)(kW2NW * kWave) : (unsigned)kWave;
+  return waveGroups(mode, m) ? (unsigned)(m->w2NW * kWave) : (unsigned)kWave;
 }
 
 // more than 448 states: the any-K kernel (fsmc_kernels_any.h)
@@ -367,19 +384,16 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
     if (mode == kModeIbd) {
       m->ctx->lastStride = 1;
     }
-    m->ctx->lastMember = 1000 + m->KP / kW2NW; // 1048 ... 1112: four waves per group, 48 ... 112 states per wave
-    switch (m->KP / kW2NW) {
-    case 48:
-      return pickWaveGroupKernel<48>(mode, track, m->sequence != 0);
-    case 64:
-      return pickWaveGroupKernel<64>(mode, track, m->sequence != 0);
-    case 80:
-      return pickWaveGroupKernel<80>(mode, track, m->sequence != 0);
-    case 96:
-      return pickWaveGroupKernel<96>(mode, track, m->sequence != 0);
-    default:
-      return pickWaveGroupKernel<112>(mode, track, m->sequence != 0);
-    }
+    const int NW = m->w2NW, KH = m->KP / NW;
+    // 1048 ... 1112: four waves per group of 48 ... 112 states; 5064 ... 8064: five ... eight waves of 64
+    m->ctx->lastMember = NW == kW2NW ? 1000 + KH : 1000 * NW + KH;
+#define FSMC_PICK_W2(KHX, NWX)                                                                                          \
+  if (KH == KHX && NW == NWX) {                                                                                        \
+    return pickWaveGroupKernel<KHX, NWX>(mode, track, m->sequence != 0);                                               \
+  }
+    FSMC_ALL_W2(FSMC_PICK_W2)
+#undef FSMC_PICK_W2
+    return nullptr;
   }
   const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1; // (also with two half-groups per wave)
   if (mode == kModeIbd) {
@@ -1010,8 +1024,10 @@ int fsmc_model_create(fsmc_ctx* ctx, const fsmc_model_desc* d, fsmc_model** out)
   m->K = d->K;
   m->KP = (d->K + kKPad - 1) / kKPad * kKPad; // rows zero padded to whole operand blocks of any tunable width
   if (d->K > 128 && d->K <= kMaxStatesW2) {
-    // wide models: four waves per group hold KP/4 states each (fsmc_kernels_w2.h); the padding states are ghosts
-    m->KP = d->K <= 192 ? 192 : d->K <= 256 ? 256 : d->K <= 320 ? 320 : d->K <= 384 ? 384 : 448;
+    // wide models: NW waves per group hold KP / NW states each (fsmc_kernels_w2.h); the padding states are ghosts
+    const W2Member w = w2Member(d->K);
+    m->w2NW = w.NW;
+    m->KP = w.NW * w.KH;
   }
   m->S = d->S;
   m->nRows = d->n_rows;

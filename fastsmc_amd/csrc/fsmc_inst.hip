@@ -1,6 +1,7 @@
 // fsmc_inst.hip -- one family member's kernel instantiations (see fsmc_instances.h).
 // Compiled with -DFSMC_INSTANCE_KT=<n> (lane-per-pair member) or -DFSMC_INSTANCE_W2=<n> (states per wave of the
-// four-waves-per-group kernel); fastsmc_amd/build.py drives one hipcc per member, in parallel.
+// wave-group kernel; -DFSMC_INSTANCE_NW=<waves per group>, four if not given); fastsmc_amd/build.py drives one hipcc
+// per member, in parallel.
 #include "fsmc_instances.h"
 
 namespace fsmc
@@ -15,7 +16,10 @@ static_assert(halfBuilt(FSMC_INSTANCE_KT), "not a member of the library: add it 
 FSMC_KT_HALF_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
 FSMC_DEFINE_KT_DUAL_HALF(FSMC_INSTANCE_KT)
 #elif defined(FSMC_INSTANCE_W2)
-FSMC_W2_KERNELS(FSMC_DEFINE_W2, FSMC_INSTANCE_W2)
+#ifndef FSMC_INSTANCE_NW
+#define FSMC_INSTANCE_NW 4
+#endif
+FSMC_W2_KERNELS(FSMC_DEFINE_W2, FSMC_INSTANCE_W2, FSMC_INSTANCE_NW)
 #else
 #error "define FSMC_INSTANCE_KT or FSMC_INSTANCE_W2"
 #endif

@@ -12,9 +12,10 @@
 //   exact members (FSMC_EXACT_KT, default 50 and 100; any K that is not a multiple of 16 may be listed at build time:
 //   `FSMC_EXACT_MEMBERS="50 100 75" python -m fastsmc_amd.build`): a model of exactly that many states runs without
 //   ghost states, masks and run-time state counts -- what the 69-state member is to the reference's own files
-// Wave-group kernel (decode_kernel_w2<KH, MODE, TRACK, SEQ>), lane = pair and four waves per group: 128 < K <= 256,
-//   KH = 48, 64 states per wave.
-// Any-K kernel (decode_kernel_any<MODE, TRACK, SEQ>, fsmc_kernels_any.h): K > 256, a pair's K-vectors in the workspace
+// Wave-group kernel (decode_kernel_w2<KH, MODE, TRACK, SEQ, NW>), lane = pair and NW waves per group of KH states each:
+//   128 < K <= 256: four waves of 48 or 64 states; 256 < K <= 320: four waves of 80; 320 < K <= 512: six, seven or
+//   eight waves of 64.
+// Any-K kernel (decode_kernel_any<MODE, TRACK, SEQ>, fsmc_kernels_any.h): K > 512, a pair's K-vectors in the workspace
 //   instead of registers -- correct, not fast; small enough to be instantiated where it is picked (fsmc_capi.hip).
 // (The runtime-K instantiation KT = 0 and the four-lanes-per-pair kernel of earlier builds are gone: every model of at
 //  most 256 states, in every mode, runs one of the two families above.)
@@ -76,25 +77,26 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_DEFINE_KT_DUAL_HALF(KT)                                                                                   \
   template __global__ void decode_kernel<KT, kModeIbd, true, false, true, true>(const KParams);                      \
   template __global__ void decode_kernel<KT, kModeIbd, false, false, true, true>(const KParams);
-// four waves per group, lane = pair (fsmc_kernels_w2.h): 128 < K <= 256, KH = 48, 64 states per wave
-#define FSMC_W2_KERNELS(X, KH)                                                                                         \
-  X(KH, kModeIbd, true, false)                                                                                         \
-  X(KH, kModeIbd, false, false)                                                                                        \
-  X(KH, kModeDump, false, false)                                                                                       \
-  X(KH, kModeSums, false, false)                                                                                       \
-  X(KH, kModePerPair, false, false)                                                                                    \
-  X(KH, kModeIbd, true, true)                                                                                          \
-  X(KH, kModeIbd, false, true)                                                                                         \
-  X(KH, kModeDump, false, true)                                                                                        \
-  X(KH, kModeSums, false, true)                                                                                        \
-  X(KH, kModePerPair, false, true)
-#define FSMC_DECLARE_W2(KH, MODE, TRACK, SEQ)                                                                          \
-  extern template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ>(const KParams);
-#define FSMC_DEFINE_W2(KH, MODE, TRACK, SEQ) template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ>(const KParams);
+// NW waves per group of KH states each, lane = pair (fsmc_kernels_w2.h): 128 < K <= 512
+#define FSMC_W2_KERNELS(X, KH, NW)                                                                                     \
+  X(KH, kModeIbd, true, false, NW)                                                                                     \
+  X(KH, kModeIbd, false, false, NW)                                                                                    \
+  X(KH, kModeDump, false, false, NW)                                                                                   \
+  X(KH, kModeSums, false, false, NW)                                                                                   \
+  X(KH, kModePerPair, false, false, NW)                                                                                \
+  X(KH, kModeIbd, true, true, NW)                                                                                      \
+  X(KH, kModeIbd, false, true, NW)                                                                                     \
+  X(KH, kModeDump, false, true, NW)                                                                                    \
+  X(KH, kModeSums, false, true, NW)                                                                                    \
+  X(KH, kModePerPair, false, true, NW)
+#define FSMC_DECLARE_W2(KH, MODE, TRACK, SEQ, NW)                                                                      \
+  extern template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ, NW>(const KParams);
+#define FSMC_DEFINE_W2(KH, MODE, TRACK, SEQ, NW)                                                                       \
+  template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ, NW>(const KParams);
 
 // every member of the library (build.py compiles fsmc_inst.hip once for each entry of these two lists)
 #define FSMC_ALL_KT(Y) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80) Y(96) Y(112) Y(128)
-#define FSMC_ALL_W2(Y) Y(48) Y(64) Y(80) Y(96) Y(112)
+#define FSMC_ALL_W2(Y) Y(48, 4) Y(64, 4) Y(80, 4) Y(64, 6) Y(64, 7) Y(64, 8)
 
 #if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_W2)
 #define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)
@@ -131,7 +133,7 @@ FSMC_DECLARE_KT_DUAL(80)
 FSMC_DECLARE_KT_DUAL(96)
 FSMC_DECLARE_KT_DUAL(112)
 FSMC_DECLARE_KT_DUAL(128)
-#define FSMC_DECLARE_W2_MEMBER(KH) FSMC_W2_KERNELS(FSMC_DECLARE_W2, KH)
+#define FSMC_DECLARE_W2_MEMBER(KH, NW) FSMC_W2_KERNELS(FSMC_DECLARE_W2, KH, NW)
 FSMC_ALL_W2(FSMC_DECLARE_W2_MEMBER)
 #endif
 

@@ -29,20 +29,16 @@
 namespace fsmc
 {
 
-constexpr int kW2NW = 4;    // waves per group
-// mailbox rows (64 floats each): carries of the recurrences per boundary, partial sums per wave
-constexpr int kW2RowT = 0, kW2RowBU = 3, kW2RowBL = 6, kW2RowC = 0, kW2RowAU = 3; // (+ boundary 0..2)
-#if defined(FSMC_W2_DIAG_OLD_LDS) // layout experiment
-constexpr int kW2RowStep = 9, kW2RowComb = 13, kW2RowLevel = 21;
-constexpr int kW2RowScan = 17;
-constexpr int kW2RowMean = kW2RowT;
-constexpr int kW2Mail = 23;
-#else
-constexpr int kW2RowStep = 9, kW2RowComb = 13, kW2RowLevel = 17;
-constexpr int kW2RowScan = kW2RowStep; // (the scan's partial sums follow the combine: the step's rows are free then)
-constexpr int kW2RowMean = kW2RowT;    // (kModePerPair: likewise the carries' rows)
-constexpr int kW2Mail = 19;
-#endif
+constexpr int kW2NW = 4;    // waves per group of the members of up to 256 (and 257 ... 320) states; NW = 6 ... 8 beyond
+constexpr int kW2MaxNW = 8;
+// mailbox rows (64 floats each): carries of the recurrences per boundary between two waves, partial sums per wave
+template <int NW> struct W2Rows {
+  static constexpr int T = 0, BU = NW - 1, BL = 2 * (NW - 1), C = 0, AU = NW - 1; // (+ boundary 0 .. NW-2)
+  static constexpr int Step = 3 * (NW - 1), Comb = Step + NW, Level = Comb + NW;   // (+ wave; Level: two rows in turn)
+  static constexpr int Scan = Step; // (the scan's partial sums follow the combine: the step's rows are free then)
+  static constexpr int Mean = T;    // (kModePerPair: likewise the carries' rows)
+  static constexpr int Mail = Level + 2;
+};
 constexpr int kWBF = 8;    // ... and of the forward pass (four tables at a time)
 constexpr int kWBWide = 8;  // ... of the passes with two operand rows (16-state blocks measured 4 % slower at 64 states per wave: spills)
 constexpr int kWB = 8;     // states per operand block of the backward passes here (two waves' roles in one kernel leave
@@ -138,8 +134,13 @@ template <int KH, int KP, int R0, int R1 = -1, int R2 = -1, int R3 = -1> struct 
   }
 };
 
+// The lambdas that take a K-vector by reference are inlined whatever their size: left to its cost model the inliner keeps
+// the site step of an eight-wave member (eight roles' code in one body) as a function, and the K-vectors -- and the
+// kernel's parameters, captured by reference -- then live in scratch memory.
+#define FSMC_W2_INLINE __attribute__((always_inline))
+
 struct W2Ctx {
-  float* mail;  // [kW2Mail][64] in LDS, shared by the waves of the group
+  float* mail;  // [W2Rows<NW>::Mail][64] in LDS, shared by the waves of the group
   int lane;
   int h;        // which wave: states [KH*h, KH*h + KH)
   bool hi;      // a wave of the upper half: descending pass first
@@ -158,22 +159,22 @@ template <int KH, int H> __device__ __forceinline__ float w2PartialSum(const flo
   }
   return s;
 }
-template <int KH, int H, int FIRST = 0>
+template <int NW, int KH, int H, int FIRST = 0>
 __device__ __forceinline__ float w2OrderedTotal(const W2Ctx& cx, const float (&v)[KH], const int row)
 {
 #pragma unroll
-  for (int ph = FIRST; ph < kW2NW; ++ph) {
+  for (int ph = FIRST; ph < NW; ++ph) {
     if (H == ph) {
       const float s = w2PartialSum<KH, H>(v, ph == 0 ? 0.f : cx.mail[(row + ph - 1) * kWave + cx.lane]);
       cx.mail[(row + ph) * kWave + cx.lane] = s;
     }
-    if (ph == kW2NW - 1) {
+    if (ph == NW - 1) {
       w2Barrier();
     } else {
       w2SumBarrier();
     }
   }
-  return cx.mail[(row + kW2NW - 1) * kWave + cx.lane];
+  return cx.mail[(row + NW - 1) * kWave + cx.lane];
 }
 #if defined(FSMC_W2_NO_MERGED_SUM) // (A/B switch: the separate first hand-over of round 3)
 constexpr int kW2SumFirst = 0;
@@ -197,12 +198,12 @@ template <int KH> __device__ __forceinline__ void w2Scale(float (&v)[KH], const 
 
 // One backward step (HMM.cpp:957-1016).  b: this wave's half of beta of site pos+1 on entry, of site pos on exit.
 // rs: the step's RowSet (all 2*KH states); e: this lane's emission values of THIS WAVE's states (LDS).
-template <int KH, int H, bool SCALE = true, bool IO = false>
+template <int NW, int KH, int H, bool SCALE = true, bool IO = false>
 __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], float (&w)[KH], cfloat_p rs,
                                              const float4* e, cfloat_p ghostMask, Diag& dg, const RowIO& out)
 {
   FSMC_END(dg, 20); // (region stamps, diagnostic builds: 0-3 work of the phases, 4-7 their barriers, 8 sum, 9 scale)
-  constexpr int KP = kW2NW * KH;
+  constexpr int KP = NW * KH;
   // 64-byte lines of this wave's part of a table row that the warm-up touches (a Touched holds four; the members of
   // more than 64 states a wave warm the first lines of their part only)
   constexpr int kLines = KH / 16 < 4 ? KH / 16 : 4;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (IO && H == kW2NW - 1) {
+      if constexpr (IO && H == NW - 1) {
         if (!accumulate) {
           rowOutPieces<KH>(out, b, blk * (BS / 4), BS / 4); // (this block of the row is about to become vec)
         }
@@ -300,8 +301,8 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
       tAbove = T[0];
     }
     if (H > 0) { // carry for the states below: (T, BU) of this wave's first state
-      cx.mail[(kW2RowT + H - 1) * kWave + cx.lane] = tAbove;
-      cx.mail[(kW2RowBU + H - 1) * kWave + cx.lane] = buAbove;
+      cx.mail[(W2Rows<NW>::T + H - 1) * kWave + cx.lane] = tAbove;
+      cx.mail[(W2Rows<NW>::BU + H - 1) * kWave + cx.lane] = buAbove;
     }
   };
   // ---- ascending pass: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  x[k] = BL[k] + D[k]*vec[k]
@@ -387,30 +388,30 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         BL = bl.y + bv.y;
       }
     }
-    if (H < kW2NW - 1) {
-      cx.mail[(kW2RowBL + H) * kWave + cx.lane] = BL; // BL of the next wave's first state
+    if (H < NW - 1) {
+      cx.mail[(W2Rows<NW>::BL + H) * kWave + cx.lane] = BL; // BL of the next wave's first state
     }
   };
 #pragma unroll
-  for (int ph = 0; ph < kW2NW; ++ph) {
+  for (int ph = 0; ph < NW; ++ph) {
     if (H == ph) { // the ascending pass reaches this wave
-      const float blIn = ph == 0 ? 0.f : cx.mail[(kW2RowBL + ph - 1) * kWave + cx.lane];
-      if ((H >= kW2NW / 2)) {
+      const float blIn = ph == 0 ? 0.f : cx.mail[(W2Rows<NW>::BL + ph - 1) * kWave + cx.lane];
+      if ((2 * H >= NW)) {
         ascending(std::integral_constant<int, kWB>{}, blIn, false); // three operand rows: the smaller blocks
       } else {
         ascending(std::integral_constant<int, kWBWide>{}, blIn, true);
       }
     }
-    if (H == kW2NW - 1 - ph) { // the descending pass reaches this wave
-      const float tIn = ph == 0 ? 0.f : cx.mail[(kW2RowT + H) * kWave + cx.lane];
-      const float buIn = ph == 0 ? 0.f : cx.mail[(kW2RowBU + H) * kWave + cx.lane];
-      if ((H >= kW2NW / 2)) {
+    if (H == NW - 1 - ph) { // the descending pass reaches this wave
+      const float tIn = ph == 0 ? 0.f : cx.mail[(W2Rows<NW>::T + H) * kWave + cx.lane];
+      const float buIn = ph == 0 ? 0.f : cx.mail[(W2Rows<NW>::BU + H) * kWave + cx.lane];
+      if ((2 * H >= NW)) {
         descending(std::integral_constant<int, kWBWide>{}, tIn, buIn, false);
       } else {
         descending(std::integral_constant<int, kWBWide>{}, tIn, buIn, true);
       }
     }
-    if constexpr (IO && H != 0 && H != kW2NW - 1) {
+    if constexpr (IO && H != 0 && H != NW - 1) {
       // the inner waves' first pass comes in phase 1: their part of the row goes out in phase 0, which they would
       // spend at the barrier (the outer waves' first pass IS phase 0: their pieces go between its operand blocks)
       if (ph == 0) {
@@ -421,7 +422,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
     // the outer waves sit out phase 1 and read the rows of their second pass in phase 3
     WarmRows<KH, KP, kRowD, kRowB, kRowUsh, kRowRR> warmInner;
     WarmRows<KH, KP, (H == 0 ? kRowUsh : kRowD), (H == 0 ? kRowRR : kRowB)> warmOuter;
-    constexpr bool outer = H == 0 || H == kW2NW - 1;
+    constexpr bool outer = H == 0 || H == NW - 1;
     if (!outer && ph == 0) {
       warmInner.request(rsw);
     }
@@ -429,8 +430,8 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
       warmOuter.request(rsw);
     }
     if constexpr (SCALE && kW2SumFirst == 1 && H == 0) {
-      if (ph == kW2NW - 1) { // wave 0's row is final: its share of the ordered sum rides on this phase's barrier
-        cx.mail[kW2RowStep * kWave + cx.lane] = w2PartialSum<KH, H>(w, 0.f);
+      if (ph == NW - 1) { // wave 0's row is final: its share of the ordered sum rides on this phase's barrier
+        cx.mail[W2Rows<NW>::Step * kWave + cx.lane] = w2PartialSum<KH, H>(w, 0.f);
       }
     }
     FSMC_END(dg, ph);
@@ -444,7 +445,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
     FSMC_END(dg, 4 + ph);
   }
   if constexpr (SCALE) {
-    const float total = w2OrderedTotal<KH, H, kW2SumFirst>(cx, w, kW2RowStep);
+    const float total = w2OrderedTotal<NW, KH, H, kW2SumFirst>(cx, w, W2Rows<NW>::Step);
     FSMC_END(dg, 8);
     w2Scale<KH>(b, w, total);
     FSMC_END(dg, 9);
@@ -457,12 +458,12 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
 }
 
 // One forward step (HMM.cpp:799-830) + scaling.  a: this wave's half of alpha of site pos-1 on entry, of pos on exit.
-template <int KH, int H, bool SCALE = true, bool IO = false>
+template <int NW, int KH, int H, bool SCALE = true, bool IO = false>
 __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], float (&w)[KH], cfloat_p rs, cfloat_p cR,
                                               const float4* e, Diag& dg, const RowIO& in)
 {
   FSMC_END(dg, 21); // (10-13 work of the phases, 14-17 their barriers, 18 sum, 19 scale)
-  constexpr int KP = kW2NW * KH;
+  constexpr int KP = NW * KH;
   constexpr int NBF = KH / kWBF;
   constexpr int kLines = KH / 16 < 4 ? KH / 16 : 4;
   static_assert(KH % kWBF == 0 && KH % 16 == 0, "whole operand blocks and lines");
@@ -536,8 +537,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
         AU = ua.y + c4[i + 1] * au.y; // AU of state k+2
       }
     }
-    if (H < kW2NW - 1) {
-      cx.mail[(kW2RowAU + H) * kWave + cx.lane] = AU; // AU of the next wave's first state
+    if (H < NW - 1) {
+      cx.mail[(W2Rows<NW>::AU + H) * kWave + cx.lane] = AU; // AU of the next wave's first state
     }
   };
   // ---- suffix sums, descending: alphaC[k] = alphaC[k+1] + alpha[k] (HMM.cpp:799-814)
@@ -580,7 +581,7 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
         w[k + 1] = bw.y;
       }
     }
-    cx.mail[(kW2RowC + H - 1) * kWave + cx.lane] = c; // alphaC of this wave's first state (H >= 2 here)
+    cx.mail[(W2Rows<NW>::C + H - 1) * kWave + cx.lane] = c; // alphaC of this wave's first state (H >= 2 here)
   };
   // lower half (w holds AU + D*alpha already): w[k] = e[k]*(w[k] + B[k]*alphaC[k+1]) on the way down
   auto finish = [&](const float cIn) {
@@ -627,31 +628,32 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
       }
     }
     if (H > 0) {
-      cx.mail[(kW2RowC + H - 1) * kWave + cx.lane] = c;
+      cx.mail[(W2Rows<NW>::C + H - 1) * kWave + cx.lane] = c;
     }
   };
 #pragma unroll
-  for (int ph = 0; ph < kW2NW; ++ph) {
+  for (int ph = 0; ph < NW; ++ph) {
     if (H == ph) { // the AU recurrence reaches this wave
-      const float auIn = ph == 0 ? 0.f : cx.mail[(kW2RowAU + ph - 1) * kWave + cx.lane];
-      if ((H >= kW2NW / 2)) {
+      const float auIn = ph == 0 ? 0.f : cx.mail[(W2Rows<NW>::AU + ph - 1) * kWave + cx.lane];
+      if ((2 * H >= NW)) {
         ascending(auIn, true);
       } else {
         ascending(auIn, false);
       }
     }
-    if (H == kW2NW - 1 - ph) { // the suffix sums reach this wave
-      const float cIn = ph == 0 ? 0.f : cx.mail[(kW2RowC + H) * kWave + cx.lane];
-      if ((H >= kW2NW / 2)) {
+    if (H == NW - 1 - ph) { // the suffix sums reach this wave
+      const float cIn = ph == 0 ? 0.f : cx.mail[(W2Rows<NW>::C + H) * kWave + cx.lane];
+      if ((2 * H >= NW)) {
         suffix(cIn);
       } else {
         finish(cIn);
       }
     }
     if constexpr (IO) {
-      // the next beta row is requested in the phases a wave would spend at the barrier: the outer waves work in phases
-      // 0 and 3, the inner ones in phases 1 and 2 -- half a row in each idle phase (the combine is a sum pass away)
-      constexpr bool outer = H == 0 || H == kW2NW - 1;
+      // the next beta row is requested in the phases a wave would spend at the barrier: the outer waves work in the first
+      // and the last phase, the inner ones in between (four waves: phases 1 and 2) -- half a row in each of two idle
+      // phases (the combine is a sum pass away)
+      constexpr bool outer = H == 0 || H == NW - 1;
 #if defined(FSMC_W2_ROWIN_EARLY) // (experiment: the whole row in a wave's FIRST idle phase)
       if ((outer && ph == 1) || (!outer && ph == 0)) {
         rowInPieces(in, 0, KH / 4);
@@ -660,7 +662,7 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
       if ((outer && ph == 1) || (!outer && ph == 0)) {
         rowInPieces(in, 0, KH / 8);
       }
-      if ((outer && ph == 2) || (!outer && ph == 3)) {
+      if ((outer && ph == 2) || (!outer && ph == NW - 1)) {
         rowInPieces(in, KH / 8, KH / 4 - KH / 8);
       }
 #endif
@@ -670,7 +672,7 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     // one row for every step: always cached)
     WarmRows<KH, KP, kRowD, kRowU, kRowB> warmInner;
     WarmRows<KH, KP, (H == 0 ? kRowB : kRowD), (H == 0 ? -1 : kRowU)> warmOuter;
-    constexpr bool outerA = H == 0 || H == kW2NW - 1;
+    constexpr bool outerA = H == 0 || H == NW - 1;
     if (!outerA && ph == 0) {
       warmInner.request(rsw);
     }
@@ -678,8 +680,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
       warmOuter.request(rsw);
     }
     if constexpr (SCALE && kW2SumFirst == 1 && H == 0) {
-      if (ph == kW2NW - 1) { // (as in the backward step: wave 0's share of the ordered sum rides on this barrier)
-        cx.mail[kW2RowStep * kWave + cx.lane] = w2PartialSum<KH, H>(w, 0.f);
+      if (ph == NW - 1) { // (as in the backward step: wave 0's share of the ordered sum rides on this barrier)
+        cx.mail[W2Rows<NW>::Step * kWave + cx.lane] = w2PartialSum<KH, H>(w, 0.f);
       }
     }
     FSMC_END(dg, 10 + ph);
@@ -693,7 +695,7 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
     FSMC_END(dg, 14 + ph);
   }
   if constexpr (SCALE) {
-    const float total = w2OrderedTotal<KH, H, kW2SumFirst>(cx, w, kW2RowStep);
+    const float total = w2OrderedTotal<NW, KH, H, kW2SumFirst>(cx, w, W2Rows<NW>::Step);
     FSMC_END(dg, 18);
     w2Scale<KH>(a, w, total);
     FSMC_END(dg, 19);
@@ -707,17 +709,32 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 
 // The wave's role is a compile-time parameter of the step functions (its phases are then straight-line code); the
 // kernel branches on the wave number once per call.
+// (the last wave's role is the switch's default: the compiler need not prove h < NW)
+#define FSMC_W2_ROLE_CASE(n, CALL)                                                                                     \
+  if constexpr (n < NW - 1) {                                                                                          \
+    if (h_ == n) {                                                                                                     \
+      constexpr int H = n;                                                                                             \
+      CALL;                                                                                                            \
+      break;                                                                                                           \
+    }                                                                                                                  \
+  }
 #define FSMC_W2_ROLE(h, CALL)                                                                                          \
   do {                                                                                                                 \
-    switch (h) {                                                                                                       \
-    case 0: { constexpr int H = 0; CALL; } break;                                                                      \
-    case 1: { constexpr int H = 1; CALL; } break;                                                                      \
-    case 2: { constexpr int H = 2; CALL; } break;                                                                      \
-    default: { constexpr int H = 3; CALL; } break;                                                                     \
+    const int h_ = (h);                                                                                                \
+    FSMC_W2_ROLE_CASE(0, CALL)                                                                                         \
+    FSMC_W2_ROLE_CASE(1, CALL)                                                                                         \
+    FSMC_W2_ROLE_CASE(2, CALL)                                                                                         \
+    FSMC_W2_ROLE_CASE(3, CALL)                                                                                         \
+    FSMC_W2_ROLE_CASE(4, CALL)                                                                                         \
+    FSMC_W2_ROLE_CASE(5, CALL)                                                                                         \
+    FSMC_W2_ROLE_CASE(6, CALL)                                                                                         \
+    {                                                                                                                  \
+      constexpr int H = NW - 1;                                                                                        \
+      CALL;                                                                                                            \
     }                                                                                                                  \
   } while (0)
 
-// Work item = one group of <= 64 pairs; workgroup = kW2NW waves; two workgroups per CU (the landing zones fill LDS).
+// Work item = one group of <= 64 pairs; workgroup = NW waves; two workgroups per CU (the landing zones fill LDS).
 // SEQ: sequence mode (two steps per site, a fourth emission row per site: fsmc_kernels.h) -- the same schedule as there.
 // (-DFSMC_W2_WG_PER_CU=1, an experiment: one workgroup per CU gets 512 registers a lane -- 256 + 102 accumulation
 //  registers, no scratch instead of 165 spilled -- and runs 1.43 times faster by itself, but the CU then idles in the two
@@ -725,16 +742,19 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 #ifndef FSMC_W2_WG_PER_CU
 #define FSMC_W2_WG_PER_CU 2
 #endif
-// Members of more than 64 states a wave (KH = 80 ... 128: models of 257 ... 512 states) run ONE workgroup per CU: their
-// landing zones alone are 80 ... 128 KiB of the CU's 160, and a wave has the whole 512-entry register file (256
-// registers + accumulation registers for what the allocator has to park).
-constexpr int w2WorkgroupsPerCU(int KH) { return KH <= 64 ? FSMC_W2_WG_PER_CU : 1; }
-template <int KH, int MODE, bool TRACK, bool SEQ = false>
-__global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_kernel_w2(const KParams p)
+// Members of more than 64 states a wave (KH = 80 ... 112: models of 257 ... 448 states in four waves) run ONE workgroup
+// per CU: their landing zones alone are 80 ... 112 KiB of the CU's 160, and a wave has the whole 512-entry register file
+// (256 registers + accumulation registers for what the allocator has to park).  So do the groups of more than four
+// waves (NW = 5 ... 8 of 64 states: 257 ... 512 states; landing zones of 80 ... 128 KiB; five or more waves a CU leave a
+// wave 256 registers, the four-wave 64-state member's budget).
+constexpr int w2WorkgroupsPerCU(int KH, int NW = kW2NW) { return NW == kW2NW && KH <= 64 ? FSMC_W2_WG_PER_CU : 1; }
+template <int KH, int MODE, bool TRACK, bool SEQ = false, int NW = kW2NW>
+__global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_kernel_w2(const KParams p)
 {
+  static_assert(NW >= 4 && NW <= kW2MaxNW, "waves per group");
   static_assert(MODE == kModeIbd || MODE == kModeDump || MODE == kModeSums || MODE == kModePerPair,
                 "the consumers of the wave-group kernel");
-  constexpr int KP = kW2NW * KH;
+  constexpr int KP = NW * KH;
   constexpr int K4H = KH / 4;        // float4 per lane of this wave's part of a K-vector
   constexpr int NC = SEQ ? 4 : 3;    // emission rows per site: three observation classes (+ the gap's homozygous row)
   // The rows of the three observation classes lie one float4 further apart than their length (array mode): K4H * 16 B is
@@ -750,13 +770,13 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
 #endif
   constexpr int E4H = NC * ERS;      // float4 of one site's emission values of this wave's states (+ padding)
   constexpr int NLE = (E4H + kWave - 1) / kWave;
-  __shared__ float4 emisLds[kW2NW][2][E4H];       // [wave][ring slot][class * K4H + k4]
-  __shared__ float4 betaLds[kW2NW][K4H * kWave];  // [wave]: landing zone of the next site's beta row (its part)
-  __shared__ float mailLds[kW2Mail * kWave];
+  __shared__ float4 emisLds[NW][2][E4H];       // [wave][ring slot][class * K4H + k4]
+  __shared__ float4 betaLds[NW][K4H * kWave];  // [wave]: landing zone of the next site's beta row (its part)
+  __shared__ float mailLds[W2Rows<NW>::Mail * kWave];
   __shared__ float4 piLds[KP / 4];   // initialStateProb, zero padded
   __shared__ float4 coalLds[MODE == kModePerPair ? KP / 4 : 1]; // kModePerPair: expected coalescence times, zero padded
   __shared__ unsigned groupLds;
-  __shared__ unsigned char clsLds[kW2NW][kWave]; // kModeSums: observation class of every pair at the current site
+  __shared__ unsigned char clsLds[NW][kWave]; // kModeSums: observation class of every pair at the current site
   // Per-lane bookkeeping that lives for a whole group sits in LDS, not in registers: the XOR / AND words of the
   // current 64 sites of every pair and the table rows of the steps into those sites.  (As registers they were the
   // values the allocator spilled in the site loops -- reloaded from scratch memory at every site behind a vmcnt(0),
@@ -770,7 +790,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
   const int lane = threadIdx.x & (kWave - 1);
   // (wave-uniform BY CONSTRUCTION: as a scalar the compiler branches on it instead of predicating both roles)
   const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const W2Ctx cx = {mailLds, lane, h, h >= kW2NW / 2};
+  const W2Ctx cx = {mailLds, lane, h, 2 * h >= NW};
   const int K = p.K; // states of the model, <= KP
   const cfloat_p tPi = (cfloat_p)p.pi, tExpT = (cfloat_p)p.expT;
   const size_t vecF4 = (size_t)(KP / 4) * kWave; // float4 per stored K-vector of the group
@@ -909,7 +929,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
         waitVm0();
       }
     };
-    auto storeHalf = [&](float4* row, const float (&v)[KH]) { // row: wave-uniform address of the stored vector
+    auto storeHalf = [&](float4* row, const float (&v)[KH]) FSMC_W2_INLINE { // row: wave-uniform address of the stored vector
       const gchar_p base = uniformPtr(row + halfF4);
 #pragma unroll
       for (int k4 = 0; k4 < K4H; ++k4) {
@@ -917,7 +937,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
         __builtin_nontemporal_store(ov, rowSlot(base, k4, laneOff));
       }
     };
-    auto loadHalf = [&](const float4* row, float (&v)[KH]) {
+    auto loadHalf = [&](const float4* row, float (&v)[KH]) FSMC_W2_INLINE {
       const gchar_p base = uniformPtr(row + halfF4);
 #pragma unroll
       for (int k4 = 0; k4 < K4H; ++k4) {
@@ -939,7 +959,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
     };
     // beta at the last site of the window: all ones, scaled (HMM.cpp:887-897): 1.0f / K for a state of the model
     // (K sequential additions of 1.0f are exact), +0 for a ghost
-    auto betaInit = [&](float (&b)[KH]) {
+    auto betaInit = [&](float (&b)[KH]) FSMC_W2_INLINE {
       const float c = 1.0f / (float)K;
 #pragma unroll
       for (int k = 0; k < KH; ++k) {
@@ -948,27 +968,27 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
     };
     // beta of site q -> beta of site q-1.  OUT: the row the step starts from -- beta of site q -- goes to `outRow` piece
     // by piece during the step (RowIO)
-    auto betaStepInto = [&](float (&b)[KH], float (&w)[KH], const int q, auto moveRow, float4* outRow) {
+    auto betaStepInto = [&](float (&b)[KH], float (&w)[KH], const int q, auto moveRow, float4* outRow) FSMC_W2_INLINE {
       constexpr bool OUT = decltype(moveRow)::value;
       const int c = obsClass(q);
       const cfloat_p rsq = rowSetOfRow(SEQ ? __builtin_amdgcn_readfirstlane(p.rowSiteB[q]) : stepRowOf(q));
       const float4* eq = &emisLds[h][q & 1][c * ERS];
       const RowIO out = {OUT ? uniformPtr(outRow + halfF4) : (gchar_p) nullptr, laneOff, nullptr};
-      FSMC_W2_ROLE(h, (beta_step_w2<KH, H, true, OUT>(cx, b, w, rsq, eq, ghostMask, cycW, out)));
+      FSMC_W2_ROLE(h, (beta_step_w2<NW, KH, H, true, OUT>(cx, b, w, rsq, eq, ghostMask, cycW, out)));
     };
     // a spare row of the workspace (checkpoint slot 0 is never a checkpoint): where an OUT step without a row of its
     // own to store writes
     float4* const spareRow = ckpt;
     // sequence mode: the un-normalised half-step across the gap (q-1, q), with the homozygous emission row of site q
     // (the fourth row of its ring slot)
-    auto betaGapStep = [&](float (&b)[KH], float (&w)[KH], const int q) {
+    auto betaGapStep = [&](float (&b)[KH], float (&w)[KH], const int q) FSMC_W2_INLINE {
       const cfloat_p rsq = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapB[q]));
       const float4* eq = &emisLds[h][q & 1][3 * ERS];
-      FSMC_W2_ROLE(h, (beta_step_w2<KH, H, false>(cx, b, w, rsq, eq, ghostMask, cycW, noRowIO())));
+      FSMC_W2_ROLE(h, (beta_step_w2<NW, KH, H, false>(cx, b, w, rsq, eq, ghostMask, cycW, noRowIO())));
     };
     // the site step out of q = pos+1 (its rows are in the ring), then the half-step towards pos-1 unless pos is the
     // window start; the vector carried from site to site is the STORED one (after the half-step)
-    auto betaSeqStep = [&](float (&b)[KH], float (&w)[KH], const int pos) {
+    auto betaSeqStep = [&](float (&b)[KH], float (&w)[KH], const int pos) FSMC_W2_INLINE {
       const int q = pos + 1;
       waitVm0(); // the rows of site q have landed
       __builtin_amdgcn_wave_barrier();
@@ -1182,7 +1202,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
             w[4 * k4 + 3] = pv.w * ev.w;
           }
           float total = 0.f;
-          FSMC_W2_ROLE(h, (total = w2OrderedTotal<KH, H>(cx, w, kW2RowStep)));
+          FSMC_W2_ROLE(h, (total = w2OrderedTotal<NW, KH, H>(cx, w, W2Rows<NW>::Step)));
           // (alpha_init multiplies by 1.0f / sum as well, HMM.cpp:744-747)
           w2Scale<KH>(a, w, total);
         } else {
@@ -1192,9 +1212,9 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
           // the same bytes.  The sums consumer transposes its tile through the zone and requests the next row itself.)
           if constexpr (MODE != kModeSums) {
             const RowIO in = {uniformPtr(chunkbuf + (size_t)(pos - lo) * vecF4 + halfF4), laneOff, &betaLds[h][0]};
-            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H, true, true>(cx, a, w, rsp, tCR, e, cycW, in)));
+            FSMC_W2_ROLE(h, (alpha_step_w2<NW, KH, H, true, true>(cx, a, w, rsp, tCR, e, cycW, in)));
           } else {
-            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H>(cx, a, w, rsp, tCR, e, cycW, noRowIO())));
+            FSMC_W2_ROLE(h, (alpha_step_w2<NW, KH, H>(cx, a, w, rsp, tCR, e, cycW, noRowIO())));
           }
         }
         if constexpr (SEQ) {
@@ -1205,7 +1225,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
             __builtin_amdgcn_wave_barrier();
             const cfloat_p rsg = rowSetOfRow(__builtin_amdgcn_readfirstlane(p.rowGapF[pos + 1]));
             const float4* eg = &emisLds[h][(pos + 1) & 1][3 * ERS];
-            FSMC_W2_ROLE(h, (alpha_step_w2<KH, H, false>(cx, a, w, rsg, tCR, eg, cycW, noRowIO())));
+            FSMC_W2_ROLE(h, (alpha_step_w2<NW, KH, H, false>(cx, a, w, rsg, tCR, eg, cycW, noRowIO())));
           }
         }
         // combine with beta of this site (landed in LDS) and normalise (HMM.cpp:672-691)
@@ -1258,7 +1278,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
         }
         FSMC_END(cycW, 22);
         float sumq = 0.f;
-        FSMC_W2_ROLE(h, (sumq = w2OrderedTotal<KH, H>(cx, w, kW2RowComb)));
+        FSMC_W2_ROLE(h, (sumq = w2OrderedTotal<NW, KH, H>(cx, w, W2Rows<NW>::Comb)));
         const float cq = 1.0f / sumq;
         FSMC_END(cycW, 23);
         // every read of this site's ring slot has returned (the barriers above waited for lgkmcnt(0)): request the rows of
@@ -1357,12 +1377,12 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
           float mean = 0.f, best = 0.f;
           int arg = 0;
 #pragma unroll
-          for (int ph = 0; ph < kW2NW; ++ph) {
+          for (int ph = 0; ph < NW; ++ph) {
             if (h == ph) {
               if (ph > 0) {
-                mean = cx.mail[(kW2RowMean + ph - 1) * kWave + lane];
-                best = cx.mail[(kW2RowStep + ph - 1) * kWave + lane];
-                arg = __float_as_int(cx.mail[(kW2RowComb + ph - 1) * kWave + lane]);
+                mean = cx.mail[(W2Rows<NW>::Mean + ph - 1) * kWave + lane];
+                best = cx.mail[(W2Rows<NW>::Step + ph - 1) * kWave + lane];
+                arg = __float_as_int(cx.mail[(W2Rows<NW>::Comb + ph - 1) * kWave + lane]);
               }
 #pragma unroll
               for (int k4 = 0; k4 < K4H; ++k4) {
@@ -1378,17 +1398,17 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
                   }
                 }
               }
-              if (ph < kW2NW - 1) {
-                cx.mail[(kW2RowMean + ph) * kWave + lane] = mean;
-                cx.mail[(kW2RowStep + ph) * kWave + lane] = best;
-                cx.mail[(kW2RowComb + ph) * kWave + lane] = __int_as_float(arg);
+              if (ph < NW - 1) {
+                cx.mail[(W2Rows<NW>::Mean + ph) * kWave + lane] = mean;
+                cx.mail[(W2Rows<NW>::Step + ph) * kWave + lane] = best;
+                cx.mail[(W2Rows<NW>::Comb + ph) * kWave + lane] = __int_as_float(arg);
               }
             }
-            if (ph < kW2NW - 1) {
+            if (ph < NW - 1) {
               w2Barrier();
             }
           }
-          if (h == kW2NW - 1 && isValid()) {
+          if (h == NW - 1 && isValid()) {
             if (p.ppMean) p.ppMean[(size_t)pairIndex() * p.S + pos] = mean;
             if (p.ppMap) p.ppMap[(size_t)pairIndex() * p.S + pos] = arg;
           }
@@ -1409,21 +1429,25 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
             // sum over the states below the threshold, k ascending from 0.f (HMM.cpp:1207-1224): wave 0 first, the next
             // waves join only when the threshold reaches their states (uniform over the launch)
             const unsigned nPost = p.stateThr;
-            const int nScanWaves = nPost > 3u * KH ? 4 : nPost > 2u * KH ? 3 : nPost > (unsigned)KH ? 2 : 1;
+            int nScanWaves = 1;
+#pragma unroll
+            for (int i = 1; i < NW; ++i) {
+              nScanWaves += nPost > (unsigned)(i * KH) ? 1 : 0;
+            }
             float s = 0.f;
             // (this wave's states below the threshold: scanBlocks, fsmc_kernels.h)
             auto partial = [&](float s0) -> float {
               const unsigned nLocal = nPost - (unsigned)(h * KH) < (unsigned)KH ? nPost - (unsigned)(h * KH) : (unsigned)KH;
-              scanBlocks<KH, KH, K4H>(w, s0, cq, launderScalar(nLocal));
+              scanBlocks<KH, KH, K4H>(w, s0, cq, launderScalar((unsigned)__builtin_amdgcn_readfirstlane((int)nLocal)));
               return s0;
             };
 #pragma unroll
-            for (int ph = 0; ph < kW2NW; ++ph) {
+            for (int ph = 0; ph < NW; ++ph) {
               if (ph < nScanWaves) {
                 if (h == ph) {
-                  s = partial(ph == 0 ? 0.f : cx.mail[(kW2RowScan + ph - 1) * kWave + lane]);
+                  s = partial(ph == 0 ? 0.f : cx.mail[(W2Rows<NW>::Scan + ph - 1) * kWave + lane]);
                   if (nScanWaves > 1) {
-                    cx.mail[(kW2RowScan + ph) * kWave + lane] = s;
+                    cx.mail[(W2Rows<NW>::Scan + ph) * kWave + lane] = s;
                   }
                 }
                 if (nScanWaves > 1) {
@@ -1432,7 +1456,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
               }
             }
             if (nScanWaves > 1) {
-              s = cx.mail[(kW2RowScan + nScanWaves - 1) * kWave + lane];
+              s = cx.mail[(W2Rows<NW>::Scan + nScanWaves - 1) * kWave + lane];
             }
             FSMC_END(cycW, 26); // (the scan's sum)
             // the scan's state machine runs in wave 0 (lane = pair)
@@ -1447,7 +1471,7 @@ __global__ __launch_bounds__(kW2NW * kWave, w2WorkgroupsPerCU(KH)) void decode_k
             // the other waves hold states the segment ages read: they need the decision, and wave 0 their sums
             const bool upperAges = TRACK && p.ageThr > (unsigned)KH;
             if (upperAges) {
-              const int row = kW2RowLevel + (pos & 1); // (two rows in turn: one barrier a site is enough)
+              const int row = W2Rows<NW>::Level + (pos & 1); // (two rows in turn: one barrier a site is enough)
               if (h == 0) {
                 cx.mail[row * kWave + lane] = __int_as_float(level | (opening ? 8 : 0) | (closing ? 16 : 0));
               } else {

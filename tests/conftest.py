@@ -12,6 +12,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def wave_group_member(K):
+    """(waves per group, states per wave) of the wave-group kernel for a model of 128 < K <= 512 states, as
+    fsmc_model_create picks it (csrc/fsmc_capi.hip, w2Member): four waves of 48 / 64 / 80 states, then six, seven, eight
+    waves of 64."""
+    return ((4, 48) if K <= 192 else (4, 64) if K <= 256 else (4, 80) if K <= 320 else (6, 64) if K <= 384
+            else (7, 64) if K <= 448 else (8, 64))
+
+
+def expected_member(K):
+    """What fsmc_ctx_last_kernel reports: the exact or padded family member for K <= 128; up to 512 states the
+    wave-group kernel (1000 + states per wave with four waves a group, 1000 * waves + 64 with more); beyond, 0 = the
+    any-K kernel (a pair's K-vectors in the workspace)."""
+    if K in (69, 50, 100):  # the exact members of the default build (fsmc_instances.h: FSMC_EXACT_KT)
+        return K
+    if K <= 128:
+        return (K + 15) // 16 * 16
+    if K > 512:
+        return 0
+    nw, kh = wave_group_member(K)
+    return 1000 + kh if nw == 4 else 1000 * nw + kh
+
+
 def build_small_problem():
     """A seeded synthetic problem small enough for the CPU oracle: 64 haplotypes x 640 sites, K = 69."""
     import numpy as np

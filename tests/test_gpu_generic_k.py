@@ -6,6 +6,7 @@ consumer.  Every launch is checked for the family member it ran (fsmc_ctx_last_k
 import numpy as np
 import pytest
 
+from conftest import expected_member
 from fastsmc_amd import capi, synth
 from oracle import oracle as O
 
@@ -23,16 +24,7 @@ def _problem(K, n_hap=64, S=200, seed=11):
 
 
 def _member(K, consumer="ibd"):
-    """What fsmc_ctx_last_kernel reports: the padded family member for K <= 128; up to 448 the four-waves-per-group
-    kernel (1000 + states per wave: 48 / 64 with two workgroups per CU, 80 / 96 / 112 with one); beyond, 0 = the any-K
-    kernel (a pair's K-vectors in the workspace)."""
-    if K in (69, 50, 100):  # the exact members of the default build (fsmc_instances.h: FSMC_EXACT_KT)
-        return K
-    if K <= 128:
-        return (K + 15) // 16 * 16
-    if K > 448:
-        return 0
-    return 1000 + (48 if K <= 192 else 64 if K <= 256 else 80 if K <= 320 else 96 if K <= 384 else 112)
+    return expected_member(K)  # (conftest.py)
 
 
 def _stride(K):
@@ -40,7 +32,7 @@ def _stride(K):
 
 
 @pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 49, 50, 51, 64, 65, 70, 80, 81, 99, 100, 101, 128, 130, 192, 200, 256, 257, 300, 320, 321,
-                               402, 448, 449, 520])
+                               384, 385, 402, 448, 449, 512, 513, 520])
 def test_generic_kernel_matches_oracle(K):
     pm, bits, folded = _problem(K)
     pairs = O.enumerate_all_pairs(32)[:96]
@@ -141,8 +133,8 @@ def test_wide_model_scan_thresholds_that_reach_the_upper_waves(K, time):
 
 
 def test_too_many_states_is_rejected():
-    """Up to 448 states a kernel holds a pair's vectors in registers; beyond, the any-K kernel keeps them in the workspace
-    (tested above: 449 and 520 states); the library's limit is 4096."""
+    """Up to 512 states a kernel holds a pair's vectors in registers; beyond, the any-K kernel keeps them in the workspace
+    (tested above: 513 and 520 states); the library's limit is 4096."""
     pm, bits, _ = _problem(16)
     ctx = capi.Context(0)
     import copy
@@ -156,13 +148,13 @@ def test_too_many_states_is_rejected():
     ctx.close()
 
 
-@pytest.mark.parametrize("K", [300, 402, 500])
+@pytest.mark.parametrize("K", [300, 350, 402, 500, 530])
 def test_beyond_256_states_windows_chunks_and_thresholds(K):
-    """Models of more than 256 states -- 300 and 402: the wave-group kernel with 80 / 112 states a wave, one workgroup per
-    CU; 500: the any-K kernel -- through the checkpoint / rebuild layout (explicit chunk lengths that do and do not
+    """Models of more than 256 states -- 300: the wave-group kernel with four waves of 80 states; 350, 402, 500: six,
+    seven, eight waves of 64; 530: the any-K kernel -- through the checkpoint / rebuild layout (explicit chunk lengths that do and do not
     divide the windows), windows whose scan ends before the decode window does, one- and two-site windows, ragged
     groups, with and without segment ages, and a time threshold that puts the scan's state threshold beyond 256 (the
-    scan's sum then walks all four waves of a group)."""
+    scan's sum then walks several waves of a group)."""
     tables = synth.make_model_tables(K)
     haps = synth.make_haps(64, 333, seed=K, cm_per_mb=25.0, switch_per_cm=0.6)
     bits, derived, flipped = synth.fold_and_pack(haps.alleles)

@@ -4,6 +4,7 @@ the posterior built from the vectors the reference's buffers hold after its in-p
 import numpy as np
 import pytest
 
+from conftest import expected_member, wave_group_member
 from fastsmc_amd import api, capi, synth
 from oracle import oracle as O
 
@@ -127,7 +128,7 @@ def test_per_pair_and_sums(gpu, seq_problem):
         np.testing.assert_array_equal(got, w)
 
 
-@pytest.mark.parametrize("K", [12, 100, 150, 200, 256, 260, 400, 460])
+@pytest.mark.parametrize("K", [12, 100, 150, 200, 256, 260, 340, 400, 460, 520])
 def test_generic_k_sequence(K):
     tables = synth.make_model_tables(K)
     haps = synth.make_haps(64, 150, seed=5, cm_per_mb=1.2, bp_per_site=2500, switch_per_cm=2.0)
@@ -143,11 +144,8 @@ def test_generic_k_sequence(K):
     groups = capi.whole_sequence_groups(len(pairs), pm.S)
     _assert_records_equal(ctx.decode_ibd(model, _pairs_array(pairs), groups),
                           O.decode_pairs_ibd(pm, folded, pairs, batch_size=64))
-    if K > 448:  # the any-K kernel (K-vectors in the workspace), also in sequence mode
-        assert ctx.last_kernel() == 0
-    elif K > 128:  # four waves per group (48 ... 112 states a wave), also in sequence mode
-        assert ctx.last_kernel() == 1000 + (48 if K <= 192 else 64 if K <= 256 else 80 if K <= 320 else 96 if K <= 384
-                                            else 112)
+    if K > 128:  # the wave-group kernel up to 512 states, the any-K kernel beyond, also in sequence mode
+        assert ctx.last_kernel() == expected_member(K)
     ctx.upload_worklist(_pairs_array(pairs), groups)
     post = ctx.decode_posteriors(model)
     wpost = _oracle_posterior(sp, pm, pairs[:64], 0, pm.S)
@@ -166,8 +164,8 @@ def test_generic_k_sequence(K):
         O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
         np.testing.assert_array_equal(s_, wsum)
         ctx.set_chunk_sites(32)
-        row_bytes = (192 if K <= 192 else 256 if K <= 256 else 320 if K <= 320 else 384 if K <= 384 else 448 if K <= 448
-                     else (K + 15) // 16 * 16) * 256
+        nw, kh = wave_group_member(K)
+        row_bytes = (nw * kh if K <= 512 else (K + 15) // 16 * 16) * 256
         ctx.set_workspace_limit(60 * row_bytes * 2)  # ~60 rows for each of the two groups: 150 sites do not fit
         _assert_records_equal(ctx.decode_ibd(model, _pairs_array(pairs), groups),
                               O.decode_pairs_ibd(pm, folded, pairs, batch_size=64))

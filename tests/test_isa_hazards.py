@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _compile_member(args):
     root, flags, define, out = args
-    subprocess.run(["hipcc", *flags, define, "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", out,
+    subprocess.run(["hipcc", *flags, *define.split(), "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", out,
                     os.path.join(root, "fastsmc_amd", "csrc", "fsmc_inst.hip")], check=True)
     return out
 
@@ -26,12 +26,13 @@ def test_no_instruction_touches_a_scalar_load_in_flight(tmp_path):
     sys.path.insert(0, ROOT)
     from concurrent.futures import ThreadPoolExecutor
 
-    from fastsmc_amd.build import EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, W2_MEMBERS, exact_define
+    from fastsmc_amd.build import EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, W2_MEMBERS, exact_define, w2_unit_name
 
     flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + exact_define()
     jobs = [(ROOT, flags, f"-DFSMC_INSTANCE_KT={k}", str(tmp_path / f"kt{k}.s")) for k in KT_MEMBERS + EXACT_MEMBERS]
-    # (the four-waves-per-group kernel uses the same operand loads; the four-lanes-per-pair kernel has none)
-    jobs += [(ROOT, flags, f"-DFSMC_INSTANCE_W2={k}", str(tmp_path / f"w2_{k}.s")) for k in W2_MEMBERS]
+    # (the wave-group kernel uses the same operand loads)
+    jobs += [(ROOT, flags, f"-DFSMC_INSTANCE_W2={kh} -DFSMC_INSTANCE_NW={nw}", str(tmp_path / (w2_unit_name(kh, nw) + ".s")))
+             for kh, nw in W2_MEMBERS]
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
         outs = list(ex.map(_compile_member, jobs))
     sys.path.insert(0, os.path.join(ROOT, "tools"))

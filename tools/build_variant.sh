@@ -16,8 +16,11 @@ hipcc $FLAGS "$@" -o $OBJ/capi.o $ROOT/fastsmc_amd/csrc/fsmc_capi.hip & PIDS="$P
 for K in 16 32 48 50 64 69 80 96 100 112 128; do
   hipcc $FLAGS "$@" -DFSMC_INSTANCE_KT=$K -o $OBJ/kt$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
 done
-for K in 48 64 80 96 112; do
+for K in 48 64 80; do
   hipcc $FLAGS "$@" -DFSMC_INSTANCE_W2=$K -o $OBJ/w2_$K.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
+done
+for N in 6 7 8; do
+  hipcc $FLAGS "$@" -DFSMC_INSTANCE_W2=64 -DFSMC_INSTANCE_NW=$N -o $OBJ/w2_64x$N.o $ROOT/fastsmc_amd/csrc/fsmc_inst.hip & PIDS="$PIDS $!"
 done
 hipcc $FLAGS -o $OBJ/idsort.o $ROOT/fastsmc_amd/csrc/fsmc_identify_sort.hip & PIDS="$PIDS $!"
 hipcc $FLAGS -o $OBJ/idseeds.o $ROOT/fastsmc_amd/csrc/fsmc_identify_seeds.hip & PIDS="$PIDS $!"

@@ -26,7 +26,7 @@ def demangle(names):
 
 def member(define):
     flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    r = subprocess.run(["hipcc", *flags, define, "-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+    r = subprocess.run(["hipcc", *flags, *define.split(), "-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
                         "-Wno-unused-command-line-argument", "-o", "/dev/null",
                         os.path.join(ROOT, "fastsmc_amd", "csrc", "fsmc_inst.hip")], capture_output=True, text=True)
     rows, cur = [], None
@@ -45,7 +45,7 @@ def member(define):
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_kernel_resources.json")
-    defs = [f"-DFSMC_INSTANCE_KT={k}" for k in KT_MEMBERS] + [f"-DFSMC_INSTANCE_W2={k}" for k in W2_MEMBERS]
+    defs = [f"-DFSMC_INSTANCE_KT={k}" for k in KT_MEMBERS] + [f"-DFSMC_INSTANCE_W2={kh} -DFSMC_INSTANCE_NW={nw}" for kh, nw in W2_MEMBERS]
     with ThreadPoolExecutor(max_workers=min(len(defs), os.cpu_count() or 1)) as ex:
         rows = [r for rs in ex.map(member, defs) for r in rs]
     for r, name in zip(rows, demangle([r["mangled"] for r in rows])):
