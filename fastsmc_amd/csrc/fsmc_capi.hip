@@ -349,7 +349,7 @@ unsigned blockThreads(int mode, const fsmc_model* m)
   return waveGroups(mode, m) ? (unsigned)(m->w2NW * kWave) : (unsigned)kWave;
 }
 
-// more than 448 states: the any-K kernel (fsmc_kernels_any.h)
+// more than 512 states: the any-K kernel (fsmc_kernels_any.h)
 bool anyStates(const fsmc_model* m)
 {
   return m->K > kMaxStatesW2;

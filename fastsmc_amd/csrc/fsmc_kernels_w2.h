@@ -742,11 +742,11 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 #ifndef FSMC_W2_WG_PER_CU
 #define FSMC_W2_WG_PER_CU 2
 #endif
-// Members of more than 64 states a wave (KH = 80 ... 112: models of 257 ... 448 states in four waves) run ONE workgroup
-// per CU: their landing zones alone are 80 ... 112 KiB of the CU's 160, and a wave has the whole 512-entry register file
-// (256 registers + accumulation registers for what the allocator has to park).  So do the groups of more than four
-// waves (NW = 5 ... 8 of 64 states: 257 ... 512 states; landing zones of 80 ... 128 KiB; five or more waves a CU leave a
-// wave 256 registers, the four-wave 64-state member's budget).
+// The member of 80 states a wave (models of 257 ... 320 states in four waves) runs ONE workgroup per CU: its landing
+// zones alone are 80 KiB of the CU's 160, and a wave has the whole 512-entry register file (256 registers +
+// accumulation registers for what the allocator has to park).  So do the groups of more than four waves (NW = 6 ... 8
+// of 64 states: 321 ... 512 states; landing zones of 96 ... 128 KiB; more than four waves a CU leave a wave 256
+// registers, the four-wave 64-state member's budget).
 constexpr int w2WorkgroupsPerCU(int KH, int NW = kW2NW) { return NW == kW2NW && KH <= 64 ? FSMC_W2_WG_PER_CU : 1; }
 template <int KH, int MODE, bool TRACK, bool SEQ = false, int NW = kW2NW>
 __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_kernel_w2(const KParams p)

@@ -162,10 +162,11 @@ int fsmc_ctx_last_resident_chunks(const fsmc_ctx* ctx, int32_t* chunks);
  * fsmc_ctx_last_items: wave work items of the last IBD launch when it paired groups, 0 when it ran them as uploaded. */
 int fsmc_ctx_set_pairing(fsmc_ctx* ctx, uint32_t mode);
 int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items);
-/* Which kernel the last launch ran: 16 ... 128 = the lane-per-pair kernel compiled for that many states (69, or the
- * padded members 16, 32, 48, 64, 80, 96, 112, 128); 1048 / 1064 = the four-waves-per-group kernel with 48 / 64 states
- * per wave (128 < K <= 256); 0 = the any-K kernel (256 < K <= 4096: a pair's K-vectors live in the workspace instead of
- * registers -- the same results, far from the roofline). */
+/* Which kernel the last launch ran: 16 ... 128 = the lane-per-pair kernel compiled for that many states (the exact
+ * members 69, 50, 100, or the padded members 16, 32, 48, 64, 80, 96, 112, 128); the wave-group kernel (128 < K <= 512):
+ * 1048 / 1064 / 1080 = four waves per group of 48 / 64 / 80 states (K <= 192 / 256 / 320), 6064 / 7064 / 8064 = six /
+ * seven / eight waves of 64 states (K <= 384 / 448 / 512); 0 = the any-K kernel (512 < K <= 4096: a pair's K-vectors
+ * live in the workspace instead of registers -- the same results, far from the roofline). */
 int fsmc_ctx_last_kernel(const fsmc_ctx* ctx, int32_t* member);
 
 /* ---- resident inputs ---- */

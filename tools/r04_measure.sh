@@ -20,6 +20,6 @@ if [ $PART = pmc ] || [ $PART = all ]; then
 fi
 if [ $PART = round ] || [ $PART = all ]; then
   bash tools/measure_round.sh r04 > gpurun_out/r04_round.log 2>&1
-  python3 tools/measure_configs.py k320 k350 k402 k448 k500 > gpurun_out/round_r04/wide_beyond_256.jsonl 2> gpurun_out/round_r04/wide_beyond_256.err
+  python3 tools/measure_configs.py k320 k350 k402 k448 k500 k600 > gpurun_out/round_r04/wide_beyond_256.jsonl 2> gpurun_out/round_r04/wide_beyond_256.err
   echo "round done"
 fi
