@@ -28,7 +28,7 @@ SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
     "fsmc_ctx_expect_work",
     "fsmc_ctx_set_chunk_sites", "fsmc_ctx_set_beta_stride", "fsmc_ctx_last_beta_stride", "fsmc_ctx_last_plan",
-    "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items", "fsmc_ctx_set_resident_chunks",
+    "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items", "fsmc_ctx_last_segment_sums_in_lds", "fsmc_ctx_set_resident_chunks",
     "fsmc_ctx_last_resident_chunks",
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
@@ -103,6 +103,7 @@ def load():
         L.fsmc_ctx_last_kernel.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_ctx_set_pairing.argtypes = [vp, u32]
         L.fsmc_ctx_last_items.argtypes = [vp, C.POINTER(i32)]
+        L.fsmc_ctx_last_segment_sums_in_lds.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_model_create.argtypes = [vp, C.POINTER(_ModelDesc), C.POINTER(vp)]
         L.fsmc_model_destroy.argtypes = [vp]
         L.fsmc_model_destroy.restype = None
@@ -219,6 +220,12 @@ class Context:
         v = C.c_int32(0)
         self._check(self._L.fsmc_ctx_last_items(self._h, C.byref(v)))
         return v.value
+
+    def last_segment_sums_in_lds(self) -> bool:
+        """The last IBD launch kept the open segments' per-state sums in LDS (a launch smaller than the chip)."""
+        v = C.c_int32(0)
+        self._check(self._L.fsmc_ctx_last_segment_sums_in_lds(self._h, C.byref(v)))
+        return bool(v.value)
 
     def set_workspace_limit(self, nbytes: int):
         self._check(self._L.fsmc_ctx_set_workspace_limit(self._h, nbytes))

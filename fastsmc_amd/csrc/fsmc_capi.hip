@@ -95,6 +95,7 @@ struct fsmc_ctx {
   uint32_t chunkSites = 0; // 0 = automatic
   uint32_t betaStride = 0; // 0 = automatic (2 where the kernel exists), 1 = store every beta row
   int lastStride = 1;
+  bool lastSpsLds = false; // the last IBD launch kept the segments' per-state sums in LDS
   int lastMember = 0; // member of the last launch: KT of the lane-per-pair kernel; wave-group kernel: 1000 + KH (four waves of KH states), 1000 * NW + KH (NW = 5 ... 8 waves)
 
   // The queues an IBD decode's waves pull from (fsmc_decode_ibd_launch): built from the uploaded groups once per
@@ -710,6 +711,7 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.wsSlot = plan.wsSlot;
   p.stateThr = m->stateThr;
   p.ageThr = m->ageThr;
+  p.spsLds = 0u;
   // int * float, evaluated in fp32 like HMM.cpp:1226,1254,1281,1308
   p.thr[0] = 1000 * m->probThr;
   p.thr[1] = 100 * m->probThr;
@@ -719,11 +721,11 @@ void fillParams(const fsmc_ctx* ctx, const fsmc_model* m, const LaunchPlan& plan
   p.recCap = (unsigned)ctx->recCap;
 }
 
-int launch(fsmc_ctx* ctx, KernelFn fn, const KParams& p, int slots, unsigned threads = kWave)
+int launch(fsmc_ctx* ctx, KernelFn fn, const KParams& p, int slots, unsigned threads = kWave, size_t dynLds = 0)
 {
   FSMC_HIP(ctx, hipMemsetAsync(ctx->dCounters, 0, 4 * sizeof(unsigned), ctx->stream));
   FSMC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(fn, dim3((unsigned)slots), dim3(threads), 0, ctx->stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)slots), dim3(threads), dynLds, ctx->stream, p);
   FSMC_HIP(ctx, hipGetLastError());
   FSMC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->timed = true;
@@ -1339,6 +1341,15 @@ int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items)
   return FSMC_OK;
 }
 
+int fsmc_ctx_last_segment_sums_in_lds(const fsmc_ctx* ctx, int32_t* in_lds)
+{
+  if (!ctx || !in_lds) {
+    return FSMC_EINVAL;
+  }
+  *in_lds = ctx->lastSpsLds ? 1 : 0;
+  return FSMC_OK;
+}
+
 int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
 {
   int rc = checkReady(ctx, m);
@@ -1439,9 +1450,27 @@ int fsmc_decode_ibd_launch(fsmc_ctx* ctx, const fsmc_model* m, uint32_t flags)
       p.ws = (float4*)ctx->wsSide.p;
     }
   }
+  // A launch smaller than the chip (one group per wave, segment ages wanted): where every wave of it still finds room, the
+  // open segments' per-state sums live in LDS instead of the workspace (fsmc_kernels.h, KParams::spsLds) -- K4 KiB of
+  // dynamic LDS a wave.  (A wave alone on its SIMD waits out every round trip of those sums to L2: C1 shape 40.6 -> 3x ms.)
+  size_t spsLdsBytes = 0;
+  if (!beside && !q.dual && track && !waveGroups(kModeIbd, m) && !anyStates(m) && !m->sequence) {
+    const int member = familyMember(m);
+    const size_t dyn = (size_t)((member > 0 ? member : m->K) + 3) / 4 * kWave * sizeof(float4);
+    hipFuncAttributes fa;
+    FSMC_HIP(ctx, hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
+    const size_t perWave = fa.sharedSizeBytes + dyn;
+    constexpr size_t kLdsPerCU = 160u << 10, kLdsPerWorkgroup = 64u << 10;
+    if (perWave <= kLdsPerWorkgroup && (size_t)plan.slots * perWave <= (size_t)ctx->nCU * kLdsPerCU &&
+        (size_t)plan.slots <= (size_t)ctx->nCU * (kLdsPerCU / perWave) && !std::getenv("FSMC_DIAG_NO_SPS_LDS")) {
+      spsLdsBytes = dyn;
+      p.spsLds = 1u;
+    }
+  }
+  ctx->lastSpsLds = spsLdsBytes != 0;
   rc = beside ? launchBeside(ctx, fn, p, plan.slots, fnDual, pDual, planDual.slots)
               : q.dual ? launch(ctx, fnDual, pDual, planDual.slots)
-                       : launch(ctx, fn, p, plan.slots, blockThreads(kModeIbd, m));
+                       : launch(ctx, fn, p, plan.slots, blockThreads(kModeIbd, m), spsLdsBytes);
   if (rc != FSMC_OK) {
     return rc;
   }

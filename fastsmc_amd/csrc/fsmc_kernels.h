@@ -20,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/fastsmc_hip.h"
 
 namespace fsmc
@@ -76,6 +78,7 @@ struct KParams {
   float4* ws;         // workspace, wsSlot float4 per resident wave
   size_t wsSlot;
   unsigned stateThr, ageThr;
+  unsigned spsLds; // decode_kernel, TRACK: the launch carries dynamic LDS for the open segments' per-state sums
   float thr[4];       // {1000,100,10,1} * probabilityThreshold, evaluated in fp32 (HMM.cpp:1226...)
   fsmc_ibd_record* recs;
   unsigned recCap;
@@ -787,6 +790,9 @@ template <int KT> __device__ __forceinline__ cfloat_p rowSetOf(const Tables& t, 
 // of sequence mode (posterior dump, per-pair rows, sums over pairs) keep the synchronous loads: which of their
 // instantiations are clean moved with an unrelated change to the sums consumer (64-state member), and they are not
 // worth a list of their own.  (-DFSMC_SEQ_SYNC_LOADS: synchronous everywhere, as before.)
+// The LDS home of the segments' per-state sums (KParams::spsLds) is built into the array-mode IBD decode with one group
+// per wave -- the kernel of launches that can be smaller than the chip.
+template <int MODE, bool SEQ, bool DUAL> constexpr bool kSpsLdsBuilt = MODE == kModeIbd && !SEQ && !DUAL;
 #if defined(FSMC_SEQ_SYNC_LOADS)
 template <bool SEQ, int KT, int MODE> constexpr bool kSeqSyncLoads = SEQ;
 #else
@@ -1067,8 +1073,13 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   constexpr bool kResidentBuilt = !SEQ && !DUAL && MODE == kModeIbd;
   const int nResident = kResidentBuilt ? p.residentChunks : 0;
   const int C = p.chunk;
-  // per-state posterior sums of the open segments (TRACK), one column per lane
-  float4* const spsMem = saveS + threadIdx.x;
+  // per-state posterior sums of the open segments (TRACK), one column per lane.  They live in the wave's workspace --
+  // or, when the launch leaves LDS for them (fewer waves a CU than LDS could hold: the host passes K4 x 1 KiB of dynamic
+  // LDS and sets p.spsLds), in LDS: a lane inside a segment reads and rewrites them at every site, a round trip to L2 per
+  // sixteen states that a wave alone on its SIMD waits out in full (C1 shape: 27 % of the kernel).
+  extern __shared__ float4 spsDyn[]; // [K4][64 lanes]
+  const bool spsInLds = TRACK && kSpsLdsBuilt<MODE, SEQ, DUAL> && p.spsLds != 0;
+  const float4* const spsMem = spsInLds ? (const float4*)(spsDyn + threadIdx.x) : (const float4*)(saveS + threadIdx.x);
   const unsigned laneOff = threadIdx.x * (unsigned)sizeof(float4); // this lane's byte offset inside a 1-KiB row
   // chunk-buffer slot of the row stored for the site at offset rel of its chunk
 #if defined(FSMC_DIAG_SAMEROW)
@@ -1960,41 +1971,90 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
               // per-state posterior sums of the open segment (sum_posterior_per_state, HMM.cpp:1212-1229): kept
               // in the wave's workspace, touched only by the lanes that are inside a segment at this site
               if (level != 4) {
-                // four blocks (sixteen states) per round trip: the loads of a round go out together, lanes that
-                // open a segment at this site start from zero instead of what they loaded
+                // four blocks (sixteen states) per round trip: the loads of a round go out together.  A lane that
+                // opens a segment at this site starts from zero: it clears its column first (once per segment), so
+                // that the accumulation needs no select per state; 0.f + x is x, and a wave's own store to an
+                // address is what its next load from it returns.  The products and sums go two states an instruction
+                // (the same IEEE operations): this block is executed at every site that has ANY lane of the wave
+                // inside a segment.
                 constexpr int kG = 4;
                 const gchar_p spsBase = uniformPtr(saveS); // scalar base + lane offset + immediate
+                // (the two thresholds as values the compiler cannot prove loop-invariant, like the scan's: it
+                //  otherwise hoists the compare of EVERY block out of the site loop as a lane mask in a scalar pair,
+                //  spills them all and reloads two lanes of a spill register per block and site)
+                const unsigned nAgeL = launderScalar(p.ageThr), nPostL = launderScalar(nPost);
+                auto rounds = [&](auto inLds) {
+                  constexpr bool LDS = decltype(inLds)::value;
+                  if (__builtin_expect(opening, 0)) {
 #pragma unroll
-                for (int g4 = 0; g4 < K4; g4 += kG) {
-                  if ((unsigned)(4 * g4) >= p.ageThr) {
-                    break;
-                  }
-                  float4 sv[kG];
-#pragma unroll
-                  for (int j = 0; j < kG; ++j) {
-                    if (g4 + j < K4) {
-                      const f32x4 t = *rowSlot(spsBase, g4 + j, laneOff);
-                      sv[j] = make_float4(t.x, t.y, t.z, t.w);
-                    }
-                  }
-#pragma unroll
-                  for (int j = 0; j < kG; ++j) {
-                    const int k4 = g4 + j;
-                    if (k4 < K4) {
-                      if (opening) {
-                        sv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k4 = 0; k4 < K4; ++k4) {
+                      if ((unsigned)(4 * k4) >= nAgeL) {
+                        break;
                       }
-                      // blocks the scan already normalised are taken as they are (x * 1.0f is exact); states at or
-                      // beyond the age threshold are never read back (segment_ages stops there)
-                      const float sc = ((unsigned)(4 * k4) < nPost) ? 1.0f : cq;
-                      sv[j].x = sv[j].x + w[4 * k4] * sc;
-                      if (4 * k4 + 1 < K) sv[j].y = sv[j].y + w[4 * k4 + 1] * sc;
-                      if (4 * k4 + 2 < K) sv[j].z = sv[j].z + w[4 * k4 + 2] * sc;
-                      if (4 * k4 + 3 < K) sv[j].w = sv[j].w + w[4 * k4 + 3] * sc;
-                      const f32x4 t = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
-                      *rowSlot(spsBase, k4, laneOff) = t;
+                      if constexpr (LDS) {
+                        spsDyn[k4 * kWave + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                      } else {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        *rowSlot(spsBase, k4, laneOff) = z;
+                      }
                     }
                   }
+#pragma unroll
+                  for (int g4 = 0; g4 < K4; g4 += kG) {
+                    if ((unsigned)(4 * g4) >= nAgeL) {
+                      break;
+                    }
+                    float4 sv[kG];
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) {
+                      if (g4 + j < K4) {
+                        if constexpr (LDS) {
+                          sv[j] = spsDyn[(g4 + j) * kWave + lane];
+                        } else {
+                          const f32x4 t = *rowSlot(spsBase, g4 + j, laneOff);
+                          sv[j] = make_float4(t.x, t.y, t.z, t.w);
+                        }
+                      }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) {
+                      const int k4 = g4 + j;
+                      if (k4 < K4) {
+                        // blocks the scan already normalised are taken as they are (x * 1.0f is exact); states at or
+                        // beyond the age threshold are never read back (segment_ages stops there)
+                        const float sc = ((unsigned)(4 * k4) < nPostL) ? 1.0f : cq;
+                        {
+                          if (4 * k4 + 3 < K) {
+                            const f32x2 scv = {sc, sc};
+                            const f32x2 w01 = {w[4 * k4], w[4 * k4 + 1]}, w23 = {w[4 * k4 + 2], w[4 * k4 + 3]};
+                            const f32x2 s01 = {sv[j].x, sv[j].y}, s23 = {sv[j].z, sv[j].w};
+                            const f32x2 r01 = padd(s01, pmul(w01, scv)), r23 = padd(s23, pmul(w23, scv));
+                            sv[j] = make_float4(r01.x, r01.y, r23.x, r23.y);
+                          } else {
+                            sv[j].x = sv[j].x + w[4 * k4] * sc;
+                            if (4 * k4 + 1 < K) sv[j].y = sv[j].y + w[4 * k4 + 1] * sc;
+                            if (4 * k4 + 2 < K) sv[j].z = sv[j].z + w[4 * k4 + 2] * sc;
+                            if (4 * k4 + 3 < K) sv[j].w = sv[j].w + w[4 * k4 + 3] * sc;
+                          }
+                        }
+                        if constexpr (LDS) {
+                          spsDyn[k4 * kWave + lane] = sv[j];
+                        } else {
+                          const f32x4 t = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
+                          *rowSlot(spsBase, k4, laneOff) = t;
+                        }
+                      }
+                    }
+                  }
+                };
+                if constexpr (kSpsLdsBuilt<MODE, SEQ, DUAL>) {
+                  if (spsInLds) { // (uniform over the launch)
+                    rounds(std::true_type{});
+                  } else {
+                    rounds(std::false_type{});
+                  }
+                } else {
+                  rounds(std::false_type{});
                 }
               }
             }

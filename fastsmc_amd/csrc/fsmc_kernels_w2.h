@@ -1508,9 +1508,11 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
               // per-state posterior sums of the open segment (HMM.cpp:1212-1229), each wave its own states
               if (level != 4 && (h == 0 || upperAges)) {
                 const gchar_p spsBase = uniformPtr(saveS + halfF4);
+                // (thresholds the compiler cannot prove loop-invariant: fsmc_kernels.h, same place)
+                const unsigned nAgeL = launderScalar(p.ageThr), nPostL = launderScalar(nPost);
 #pragma unroll
                 for (int k4 = 0; k4 < K4H; ++k4) {
-                  if ((unsigned)(h * KH + 4 * k4) >= p.ageThr) {
+                  if ((unsigned)(h * KH + 4 * k4) >= nAgeL) {
                     break;
                   }
                   const f32x4 t = *rowSlot(spsBase, k4, laneOff);
@@ -1518,7 +1520,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
                   if (opening) {
                     sv = make_float4(0.f, 0.f, 0.f, 0.f);
                   }
-                  const float sc = ((unsigned)(h * KH + 4 * k4) < nPost) ? 1.0f : cq;
+                  const float sc = ((unsigned)(h * KH + 4 * k4) < nPostL) ? 1.0f : cq;
                   sv.x = sv.x + w[4 * k4] * sc;
                   sv.y = sv.y + w[4 * k4 + 1] * sc;
                   sv.z = sv.z + w[4 * k4 + 2] * sc;

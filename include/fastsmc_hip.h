@@ -162,6 +162,11 @@ int fsmc_ctx_last_resident_chunks(const fsmc_ctx* ctx, int32_t* chunks);
  * fsmc_ctx_last_items: wave work items of the last IBD launch when it paired groups, 0 when it ran them as uploaded. */
 int fsmc_ctx_set_pairing(fsmc_ctx* ctx, uint32_t mode);
 int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items);
+/* 1 when the last IBD launch kept the open segments' per-state posterior sums (FSMC_WANT_MEAN / FSMC_WANT_MAP:
+ * HMM.cpp:1212-1229) in LDS instead of the workspace: a launch of fewer wavefronts than the chip's LDS can give
+ * (K/4 + 1) KiB each beside the kernel's own -- a small job, whose waves would wait out every round trip of those sums
+ * to L2.  The results do not depend on it. */
+int fsmc_ctx_last_segment_sums_in_lds(const fsmc_ctx* ctx, int32_t* in_lds);
 /* Which kernel the last launch ran: 16 ... 128 = the lane-per-pair kernel compiled for that many states (the exact
  * members 69, 50, 100, or the padded members 16, 32, 48, 64, 80, 96, 112, 128); the wave-group kernel (128 < K <= 512):
  * 1048 / 1064 / 1080 = four waves per group of 48 / 64 / 80 states (K <= 192 / 256 / 320), 6064 / 7064 / 8064 = six /
