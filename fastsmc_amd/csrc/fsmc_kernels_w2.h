@@ -1510,23 +1510,44 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
                 const gchar_p spsBase = uniformPtr(saveS + halfF4);
                 // (thresholds the compiler cannot prove loop-invariant: fsmc_kernels.h, same place)
                 const unsigned nAgeL = launderScalar(p.ageThr), nPostL = launderScalar(nPost);
+                // A lane that opens a segment at this site clears its column first (once per segment: 0.f + x is x, and
+                // a wave's own store to an address is what its next load from it returns), so the accumulation has no
+                // select; four blocks (sixteen states) per round trip to L2, their loads out together; products and sums
+                // two states an instruction -- fsmc_kernels.h, same place.  (One block a round trip, as this loop was
+                // written first, parked the wave sixteen times per site.)
+                if (__builtin_expect(opening, 0)) {
 #pragma unroll
-                for (int k4 = 0; k4 < K4H; ++k4) {
-                  if ((unsigned)(h * KH + 4 * k4) >= nAgeL) {
+                  for (int k4 = 0; k4 < K4H; ++k4) {
+                    if ((unsigned)(h * KH + 4 * k4) >= nAgeL) {
+                      break;
+                    }
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    *rowSlot(spsBase, k4, laneOff) = z;
+                  }
+                }
+                constexpr int kG = 4;
+                static_assert(K4H % kG == 0, "whole rounds");
+#pragma unroll
+                for (int g4 = 0; g4 < K4H; g4 += kG) {
+                  if ((unsigned)(h * KH + 4 * g4) >= nAgeL) {
                     break;
                   }
-                  const f32x4 t = *rowSlot(spsBase, k4, laneOff);
-                  float4 sv = make_float4(t.x, t.y, t.z, t.w);
-                  if (opening) {
-                    sv = make_float4(0.f, 0.f, 0.f, 0.f);
+                  f32x4 sv[kG];
+#pragma unroll
+                  for (int j = 0; j < kG; ++j) {
+                    sv[j] = *rowSlot(spsBase, g4 + j, laneOff);
                   }
-                  const float sc = ((unsigned)(h * KH + 4 * k4) < nPostL) ? 1.0f : cq;
-                  sv.x = sv.x + w[4 * k4] * sc;
-                  sv.y = sv.y + w[4 * k4 + 1] * sc;
-                  sv.z = sv.z + w[4 * k4 + 2] * sc;
-                  sv.w = sv.w + w[4 * k4 + 3] * sc;
-                  const f32x4 o = {sv.x, sv.y, sv.z, sv.w};
-                  *rowSlot(spsBase, k4, laneOff) = o;
+#pragma unroll
+                  for (int j = 0; j < kG; ++j) {
+                    const int k4 = g4 + j;
+                    const float sc = ((unsigned)(h * KH + 4 * k4) < nPostL) ? 1.0f : cq;
+                    const f32x2 scv = {sc, sc};
+                    const f32x2 w01 = {w[4 * k4], w[4 * k4 + 1]}, w23 = {w[4 * k4 + 2], w[4 * k4 + 3]};
+                    const f32x2 s01 = {sv[j].x, sv[j].y}, s23 = {sv[j].z, sv[j].w};
+                    const f32x2 r01 = padd(s01, pmul(w01, scv)), r23 = padd(s23, pmul(w23, scv));
+                    const f32x4 o = {r01.x, r01.y, r23.x, r23.y};
+                    *rowSlot(spsBase, k4, laneOff) = o;
+                  }
                 }
               }
             }
