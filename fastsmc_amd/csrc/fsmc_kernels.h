@@ -1977,7 +1977,11 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
                 // address is what its next load from it returns.  The products and sums go two states an instruction
                 // (the same IEEE operations): this block is executed at every site that has ANY lane of the wave
                 // inside a segment.
+                // A member that runs ONE wave per SIMD has nobody to hide a round trip behind and the accumulation
+                // registers to park other values in: all its blocks' loads go out together, one round trip a site
+                // (K = 80 on the C2 shape: 0.73 -> 0.77, K = 100: 0.69 -> 0.72).
                 constexpr int kG = 4;
+                constexpr bool kOneTrip = minWavesPerSimd(KT) == 1;
                 const gchar_p spsBase = uniformPtr(saveS); // scalar base + lane offset + immediate
                 // (the two thresholds as values the compiler cannot prove loop-invariant, like the scan's: it
                 //  otherwise hoists the compare of EVERY block out of the site loop as a lane mask in a scalar pair,
@@ -1985,6 +1989,38 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
                 const unsigned nAgeL = launderScalar(p.ageThr), nPostL = launderScalar(nPost);
                 auto rounds = [&](auto inLds) {
                   constexpr bool LDS = decltype(inLds)::value;
+                  auto loadBlock = [&](const int k4) -> float4 {
+                    if constexpr (LDS) {
+                      return spsDyn[k4 * kWave + lane];
+                    } else {
+                      const f32x4 t = *rowSlot(spsBase, k4, laneOff);
+                      return make_float4(t.x, t.y, t.z, t.w);
+                    }
+                  };
+                  // sv = the block's sums so far; adds this site's posteriors and writes the block back
+                  auto addBlock = [&](const int k4, float4 sv) {
+                    // blocks the scan already normalised are taken as they are (x * 1.0f is exact); states at or
+                    // beyond the age threshold are never read back (segment_ages stops there)
+                    const float sc = ((unsigned)(4 * k4) < nPostL) ? 1.0f : cq;
+                    if (4 * k4 + 3 < K) {
+                      const f32x2 scv = {sc, sc};
+                      const f32x2 w01 = {w[4 * k4], w[4 * k4 + 1]}, w23 = {w[4 * k4 + 2], w[4 * k4 + 3]};
+                      const f32x2 s01 = {sv.x, sv.y}, s23 = {sv.z, sv.w};
+                      const f32x2 r01 = padd(s01, pmul(w01, scv)), r23 = padd(s23, pmul(w23, scv));
+                      sv = make_float4(r01.x, r01.y, r23.x, r23.y);
+                    } else {
+                      sv.x = sv.x + w[4 * k4] * sc;
+                      if (4 * k4 + 1 < K) sv.y = sv.y + w[4 * k4 + 1] * sc;
+                      if (4 * k4 + 2 < K) sv.z = sv.z + w[4 * k4 + 2] * sc;
+                      if (4 * k4 + 3 < K) sv.w = sv.w + w[4 * k4 + 3] * sc;
+                    }
+                    if constexpr (LDS) {
+                      spsDyn[k4 * kWave + lane] = sv;
+                    } else {
+                      const f32x4 t = {sv.x, sv.y, sv.z, sv.w};
+                      *rowSlot(spsBase, k4, laneOff) = t;
+                    }
+                  };
                   if (__builtin_expect(opening, 0)) {
 #pragma unroll
                     for (int k4 = 0; k4 < K4; ++k4) {
@@ -1999,49 +2035,48 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
                       }
                     }
                   }
+                  if constexpr (kOneTrip && !LDS) {
+                    float4 sv[K4];
 #pragma unroll
-                  for (int g4 = 0; g4 < K4; g4 += kG) {
-                    if ((unsigned)(4 * g4) >= nAgeL) {
-                      break;
-                    }
-                    float4 sv[kG];
+                    for (int g4 = 0; g4 < K4; g4 += kG) {
+                      if ((unsigned)(4 * g4) < nAgeL) { // (groups of four blocks under the age threshold)
 #pragma unroll
-                    for (int j = 0; j < kG; ++j) {
-                      if (g4 + j < K4) {
-                        if constexpr (LDS) {
-                          sv[j] = spsDyn[(g4 + j) * kWave + lane];
-                        } else {
-                          const f32x4 t = *rowSlot(spsBase, g4 + j, laneOff);
-                          sv[j] = make_float4(t.x, t.y, t.z, t.w);
+                        for (int j = 0; j < kG; ++j) {
+                          if (g4 + j < K4) {
+                            sv[g4 + j] = loadBlock(g4 + j);
+                          }
                         }
                       }
                     }
 #pragma unroll
-                    for (int j = 0; j < kG; ++j) {
-                      const int k4 = g4 + j;
-                      if (k4 < K4) {
-                        // blocks the scan already normalised are taken as they are (x * 1.0f is exact); states at or
-                        // beyond the age threshold are never read back (segment_ages stops there)
-                        const float sc = ((unsigned)(4 * k4) < nPostL) ? 1.0f : cq;
-                        {
-                          if (4 * k4 + 3 < K) {
-                            const f32x2 scv = {sc, sc};
-                            const f32x2 w01 = {w[4 * k4], w[4 * k4 + 1]}, w23 = {w[4 * k4 + 2], w[4 * k4 + 3]};
-                            const f32x2 s01 = {sv[j].x, sv[j].y}, s23 = {sv[j].z, sv[j].w};
-                            const f32x2 r01 = padd(s01, pmul(w01, scv)), r23 = padd(s23, pmul(w23, scv));
-                            sv[j] = make_float4(r01.x, r01.y, r23.x, r23.y);
-                          } else {
-                            sv[j].x = sv[j].x + w[4 * k4] * sc;
-                            if (4 * k4 + 1 < K) sv[j].y = sv[j].y + w[4 * k4 + 1] * sc;
-                            if (4 * k4 + 2 < K) sv[j].z = sv[j].z + w[4 * k4 + 2] * sc;
-                            if (4 * k4 + 3 < K) sv[j].w = sv[j].w + w[4 * k4 + 3] * sc;
+                    for (int g4 = 0; g4 < K4; g4 += kG) {
+                      if ((unsigned)(4 * g4) < nAgeL) {
+#pragma unroll
+                        for (int j = 0; j < kG; ++j) {
+                          if (g4 + j < K4) {
+                            addBlock(g4 + j, sv[g4 + j]);
                           }
                         }
-                        if constexpr (LDS) {
-                          spsDyn[k4 * kWave + lane] = sv[j];
-                        } else {
-                          const f32x4 t = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
-                          *rowSlot(spsBase, k4, laneOff) = t;
+                      }
+                    }
+                  } else {
+                    // four blocks (sixteen states) per round trip
+#pragma unroll
+                    for (int g4 = 0; g4 < K4; g4 += kG) {
+                      if ((unsigned)(4 * g4) >= nAgeL) {
+                        break;
+                      }
+                      float4 sv[kG];
+#pragma unroll
+                      for (int j = 0; j < kG; ++j) {
+                        if (g4 + j < K4) {
+                          sv[j] = loadBlock(g4 + j);
+                        }
+                      }
+#pragma unroll
+                      for (int j = 0; j < kG; ++j) {
+                        if (g4 + j < K4) {
+                          addBlock(g4 + j, sv[j]);
                         }
                       }
                     }
