@@ -120,39 +120,79 @@ def node_cached_problem(n_hap: int, n_sites: int, K: int, seed: int, local_rank:
     on the way) is built ONCE per node: local rank 0 builds it and writes the prepared arrays -- the model view and the
     packed haplotypes, 0.3 GB -- to a cache file (atomic rename); the other ranks wait for the file and map it.  A
     second run on the same box (the driver's N = 2, 4, 8 in a row) finds the file.  FSMC_BENCH_CACHE names the
-    directory (default: the system's temporary directory); an unwritable directory means every rank builds its own."""
+    directory (default: $XDG_CACHE_HOME/fsmc_bench, else a per-user directory of mode 0700 under the system's temporary
+    directory); the file carries a checksum of its arrays and is ignored (and rebuilt) when it does not verify or the
+    directory is writable by others; a rank that cannot load it builds the cohort itself, and when local rank 0 cannot
+    write it leaves a `.failed` marker so that the others do not wait."""
     from fastsmc_amd import api
 
-    cache_dir = os.environ.get("FSMC_BENCH_CACHE") or os.path.join(tempfile.gettempdir(), "fsmc_bench_cache")
+    # a per-user directory nobody else can write to: the arrays in it are trusted (they shape the C3 line)
+    base = os.environ.get("FSMC_BENCH_CACHE") or os.path.join(
+        os.environ.get("XDG_CACHE_HOME") or os.path.join(tempfile.gettempdir(), f"fsmc_cache_{os.getuid()}"), "fsmc_bench")
+    cache_dir = base
     path = os.path.join(cache_dir, f"cohort_{_cache_key(n_hap, n_sites, K, seed, 'blocked')}.npz")
+    failed = path + ".failed"
+
+    def digest(arrays: dict) -> str:
+        h = hashlib.sha256()
+        for k in sorted(arrays):
+            a = np.ascontiguousarray(arrays[k])
+            h.update(k.encode())
+            h.update(str(a.dtype).encode())
+            h.update(repr(a.shape).encode())
+            h.update(a.tobytes())
+        return h.hexdigest()
 
     def load():
+        st = os.stat(cache_dir)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise OSError("cache directory is not this user's own")
         with np.load(path) as z:
-            d = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k != "__bits"}
-            bits = z["__bits"]
+            arrays = {k: z[k] for k in z.files if k != "__sha256"}
+            want = str(z["__sha256"])
+        if digest(arrays) != want:
+            raise ValueError("cohort cache: checksum mismatch")
+        bits = arrays.pop("__bits")
+        d = {k: (v if v.ndim else v.item()) for k, v in arrays.items()}
         return api.PreparedModelView(d), bits
 
+    def build_here():
+        return build_problem(n_hap, n_sites, K, seed=seed, blocked=True)[:2]
+
+    if local_rank != 0:
+        # wait for local rank 0's file (or for its word that there will be none); a file that does not load -- stale,
+        # truncated, tampered with -- is not worth a crash: build the cohort here
+        t0 = time.time()
+        while not os.path.exists(path):
+            if os.path.exists(failed) or time.time() - t0 > timeout_s:
+                return build_here()
+            time.sleep(0.2)
+        time.sleep(0.05)
+        try:
+            return load()
+        except Exception:
+            return build_here()
     if os.path.exists(path):
         try:
             return load()
         except Exception:
-            pass  # (a truncated file of a killed run: rebuild)
-    if local_rank != 0:
-        t0 = time.time()
-        while not os.path.exists(path):
-            if time.time() - t0 > timeout_s:  # (local rank 0 could not write the file: build it here after all)
-                return build_problem(n_hap, n_sites, K, seed=seed, blocked=True)[:2]
-            time.sleep(0.2)
-        time.sleep(0.05)
-        return load()
-    pm, bits, _, _ = build_problem(n_hap, n_sites, K, seed=seed, blocked=True)
+            pass  # (a truncated or foreign file: rebuild and replace it)
+    pm, bits = build_here()
     try:
-        os.makedirs(cache_dir, exist_ok=True)
+        os.makedirs(cache_dir, mode=0o700, exist_ok=True)
+        os.chmod(cache_dir, 0o700)
+        if os.path.exists(failed):
+            os.remove(failed)
+        arrays = {"__bits": np.asarray(bits), **{k: np.asarray(v) for k, v in pm.__dict__.items()}}
         tmp = f"{path}.{os.getpid()}.tmp.npz"
-        np.savez(tmp, __bits=bits, **{k: v for k, v in pm.__dict__.items()})
+        np.savez(tmp, __sha256=np.array(digest(arrays)), **arrays)
         os.replace(tmp, path)
     except OSError:
-        pass
+        try:  # the other ranks stop waiting
+            os.makedirs(cache_dir, exist_ok=True)
+            open(failed, "w").close()
+        except OSError:
+            pass
     return pm, bits
 
 
@@ -214,15 +254,62 @@ def algorithmic_bytes(n_pairs: int, S: int, K: int) -> float:
     return float(n_pairs) * S * (8 * K + 0.25)
 
 
+def _timed(fn, reps: int, ctx):
+    """One untimed pass, then `reps` timed ones: (mean kernel ms by the library's HIP events, mean wall s of the call)."""
+    ms, wall = [], []
+    for it in range(1 + reps):
+        t0 = time.perf_counter()
+        fn()
+        if it:
+            wall.append(time.perf_counter() - t0)
+            ms.append(ctx.last_kernel_ms())
+    return float(np.mean(ms)), float(np.mean(wall))
+
+
+def consumer_line(name: str, shape: str, algo: float, k_ms: float, wall_s: float, n_pairs: int, ctx, extra: dict) -> dict:
+    return {"workload": name, "shape": shape, "kernel_ms": k_ms, "call_s": wall_s, "frac": algo / (k_ms / 1e3) / HBM_PEAK,
+            "pairs_per_s_kernel": n_pairs / (k_ms / 1e3), "kernel_member": ctx.last_kernel(), "lib_hash": lib_hash(),
+            **extra}
+
+
+def c2_consumers(ctx, capi, model, pm, pairs: np.ndarray, out_budget_bytes: float = 16e9) -> list:
+    """The other posterior consumers on the headline problem, which is resident (model, haplotypes, workspace): the sum
+    over pairs of ALL pairs (HMM.cpp:1044-1085; output [sites][states], 13.8 MB) and the per-pair posterior mean + MAP
+    rows (HMM.cpp:1378-1409; 8 B per pair-site of output, which is what bounds the list: the first pairs whose rows
+    fit `out_budget_bytes`).  `frac` is on the same byte model as the headline (8K + 0.25 B per pair-site); the
+    consumer's own output bytes are stated beside it.  `call_s` is the whole C-ABI call (kernel + the copy of the
+    output to the host)."""
+    out = []
+    n_all = int(pairs.shape[0])
+    shape = f"{pm.S} sites, K={pm.K}"
+    # sums over pairs, every group a batch of 64 (the plane-ordered accumulation of DESIGN.md section 1, a9)
+    k_ms, wall = _timed(lambda: ctx.decode_sums(model), 1, ctx)
+    out.append(consumer_line("c2_sums", f"all {n_all} pairs x {shape}", algorithmic_bytes(n_all, pm.S, pm.K), k_ms, wall,
+                             n_all, ctx, {"consumer_output_bytes": 4.0 * pm.S * pm.K, "steps": 1}))
+    # per-pair mean + MAP rows
+    n_pp = int(min(n_all, out_budget_bytes / (8.0 * pm.S))) // 64 * 64
+    ctx.upload_worklist(pairs[:n_pp].view(capi.PAIR_DTYPE).reshape(-1), capi.whole_sequence_groups(n_pp, pm.S, batch=64))
+    k_ms, wall = _timed(lambda: ctx.decode_per_pair(model, pm.exp_times), 1, ctx)
+    out.append(consumer_line("c2_per_pair", f"first {n_pp} pairs ({n_pp // 64} groups on {ctx.info()['n_slots']} resident "
+                             f"waves: the rows of more pairs do not fit {out_budget_bytes / 1e9:.0f} GB) x {shape}",
+                             algorithmic_bytes(n_pp, pm.S, pm.K), k_ms, wall, n_pp, ctx,
+                             {"consumer_output_bytes": 8.0 * n_pp * pm.S, "steps": 1}))
+    return out
+
+
 def other_workloads(ctx, capi, flags: int, budget_s: float) -> list:
     """One step each of the other single-GPU configurations on the context of the headline run (its workspace is
     allocated already): C1 = the FASTSMC_EXAMPLE shape (300 haplotypes x 6760 sites, K = 69, all 44 850 pairs) as IBD
-    decode and as sum over pairs (the reference's published ASMC regression job, time_regression.py), C4 = 256
-    states x 200 000-site windows on a 256-haplotype sub-cohort (32 640 pairs).  Not part of `value`."""
+    decode, as sum over pairs (the reference's published ASMC regression job, time_regression.py), as per-pair mean +
+    MAP rows and -- its first 8192 pairs: 4K B of output per pair-site -- as full posterior dump (ASMC.decodePairs,
+    ASMC.cpp:80-128), with the CPU port timed on the same shape; C4 = 256 states x 200 000-site windows on a
+    256-haplotype sub-cohort (32 640 pairs: 510 groups = ONE round of the 512 resident workgroups) and on a 512-haplotype
+    one (130 816 pairs: 2044 groups = four rounds).  Not part of `value`."""
     out = []
     t_begin = time.perf_counter()
-    for name, (n_hap, n_sites, K), modes in (("c1", (300, 6760, 69), ("ibd", "sums")),
-                                             ("c4", (256, 200000, 256), ("ibd",))):
+    for name, (n_hap, n_sites, K), modes in (("c1", (300, 6760, 69), ("ibd", "sums", "per_pair", "dump")),
+                                             ("c4", (256, 200000, 256), ("ibd",)),
+                                             ("c4_four_rounds", (512, 200000, 256), ("ibd",))):
         if time.perf_counter() - t_begin > budget_s:
             out.append({"workload": name, "skipped": "time budget"})
             continue
@@ -230,27 +317,45 @@ def other_workloads(ctx, capi, flags: int, budget_s: float) -> list:
         pairs = all_pairs(n_hap // 2)
         model = ctx.create_model(pm)
         ctx.upload_haps(bits, pm.S)
-        ctx.upload_worklist(pairs.view(capi.PAIR_DTYPE).reshape(-1),
-                            capi.whole_sequence_groups(int(pairs.shape[0]), pm.S, batch=64))
-        algo = algorithmic_bytes(int(pairs.shape[0]), pm.S, pm.K)
+        n_all = int(pairs.shape[0])
+        shape = f"{n_hap} haplotypes x {n_sites} sites, K={pm.K}"
+
+        def use(n):
+            ctx.upload_worklist(pairs[:n].view(capi.PAIR_DTYPE).reshape(-1), capi.whole_sequence_groups(n, pm.S, batch=64))
+
         for mode in modes:
             reps = 3 if name == "c1" else 1
-            ms, n_rec = [], None
-            for it in range(1 + reps):  # one untimed pass first
-                if mode == "ibd":
+            n = min(n_all, 8192) if mode == "dump" else n_all
+            use(n)
+            extra = {"steps": reps}
+            if mode == "ibd":
+                n_rec = [0]
+
+                def run():
                     ctx.decode_ibd_launch(model, flags)
-                    n_rec = int(ctx.decode_ibd_fetch().size)
-                else:
-                    ctx.decode_sums(model)
-                if it:
-                    ms.append(ctx.last_kernel_ms())
-            k_ms = float(np.mean(ms))
-            out.append({"workload": f"{name}_{mode}",
-                        "shape": f"{n_hap} haplotypes x {n_sites} sites, K={pm.K}, all {pairs.shape[0]} pairs",
-                        "kernel_ms": k_ms, "frac": algo / (k_ms / 1e3) / HBM_PEAK, "steps": reps,
-                        "pairs_per_s_kernel": pairs.shape[0] / (k_ms / 1e3),
-                        **({"ibd_records": n_rec, "beta_stride": ctx.last_beta_stride()} if mode == "ibd" else {}),
-                        "kernel_member": ctx.last_kernel(), "lib_hash": lib_hash()})
+                    n_rec[0] = int(ctx.decode_ibd_fetch().size)
+                k_ms, wall = _timed(run, reps, ctx) if name != "c4_four_rounds" else _timed(run, 1, ctx)
+                extra.update(ibd_records=n_rec[0], beta_stride=ctx.last_beta_stride(),
+                             groups=(n + 63) // 64, resident_waves_or_workgroups=ctx.info()["n_slots"])
+            elif mode == "sums":
+                k_ms, wall = _timed(lambda: ctx.decode_sums(model), reps, ctx)
+                extra["consumer_output_bytes"] = 4.0 * pm.S * pm.K
+            elif mode == "per_pair":
+                k_ms, wall = _timed(lambda: ctx.decode_per_pair(model, pm.exp_times), reps, ctx)
+                extra["consumer_output_bytes"] = 8.0 * n * pm.S
+            else:
+                k_ms, wall = _timed(lambda: ctx.decode_posteriors(model), reps, ctx)
+                extra["consumer_output_bytes"] = 4.0 * pm.K * 64.0 * ((n + 63) // 64) * pm.S
+                extra["groups"] = (n + 63) // 64
+            out.append(consumer_line(f"{name}_{mode}", f"{shape}, {'all' if n == n_all else 'first'} {n} pairs",
+                                     algorithmic_bytes(n, pm.S, pm.K), k_ms, wall, n, ctx, extra))
+        if name == "c1":
+            # north_star's ">= 10x the host CPU on FASTSMC_EXAMPLE-shaped input": the CPU port on this shape (IBD mode),
+            # 16 batches of 32 pairs per core
+            cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
+            cb = cpu_baseline(pm, bits, min(n_all, 16 * 32 * cores), pairs)
+            ibd = next(o for o in out if o["workload"] == "c1_ibd")
+            out.append({"workload": "c1_cpu_baseline", **cb, "gpu_kernel_over_cpu": ibd["pairs_per_s_kernel"] / cb["value"]})
         model.close()
     return out
 
@@ -264,6 +369,11 @@ def main() -> None:
                     help="auto: c2 at N = 1, c3 (strong scaling of one sharded list) at N > 1; c1: the FASTSMC_EXAMPLE "
                          "shape (300 haplotypes x 6760 sites, all 44850 pairs); c4: 256 states, 200000-site windows "
                          "(a 256-haplotype sub-cohort of config 4: 32640 pairs)")
+    ap.add_argument("--mode", choices=("ibd", "sums"), default="ibd",
+                    help="ibd: FastSMC-mode IBD decode (the headline); sums: ASMC-mode sum of the posteriors over pairs "
+                         "(HMM.cpp:1044-1085) of ONE cohort (workload c1 or c2) -- at N > 1 rank r decodes job r + 1 of N "
+                         "(the reference's own job ranges, HMM.cpp:310-321) and the planes are merged on rank 0 in rank "
+                         "order (fastsmc_amd.dist.reduce_sums: the reference's PosteriorMerger order)")
     ap.add_argument("--haps", type=int, default=0, help="haplotypes (default: the workload's)")
     ap.add_argument("--sites", type=int, default=0, help="sites (default: the workload's)")
     ap.add_argument("--pairs", type=int, default=0, help="c3: pairs in the seeded sub-list (default 2^20)")
@@ -328,10 +438,27 @@ def main() -> None:
     comm_device = "cuda" if (args.backend == "nccl" and not args.startup_only) else "cpu"
 
     from fastsmc_amd import capi
-    from fastsmc_amd.dist import all_pairs_at, gather_ibd_records, sample_pair_ordinals, shard_groups_by_weight
+    from fastsmc_amd.dist import (all_pairs_at, gather_ibd_records, reduce_sums, sample_pair_ordinals,
+                                  shard_groups_by_weight)
 
     workload = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c3")
-    if workload in ("c1", "c2", "c4"):
+    if args.mode == "sums":
+        # ONE cohort for all ranks; rank r takes job r + 1 of `world` of the reference's enumeration (HMM.cpp:319-321)
+        if workload not in ("c1", "c2"):
+            workload = "c1"
+        shape = {"c1": (300, 6760, args.states), "c2": (1000, 50000, args.states)}[workload]
+        n_hap, n_sites, n_states = args.haps or shape[0], args.sites or shape[1], shape[2]
+        pm, bits, _, _ = build_problem(n_hap, n_sites, n_states, seed=1234)
+        every_pair = all_pairs(n_hap // 2)
+        n_total = int(every_pair.shape[0])
+        lo, hi = n_total * rank // world, n_total * (rank + 1) // world
+        pairs = my_pairs = every_pair[lo:hi]
+        desc = (f"synthetic {n_hap} haplotypes x {n_sites} sites, K={pm.K}, all {n_total} pairs in {world} job(s) of the "
+                f"reference's enumeration (one per GPU), ASMC-mode sum of posteriors over pairs, merged on rank 0 in "
+                f"rank order")
+        scaling = "strong" if world > 1 else "n/a"
+        workload_key = f"{workload}_sums:{n_hap}x{n_sites}:K{pm.K}"
+    elif workload in ("c1", "c2", "c4"):
         # every rank its own cohort (only ever run at N = 1 by the driver; N > 1 here is a weak-scaling rehearsal)
         shape = {"c1": (300, 6760, args.states), "c2": (1000, 50000, args.states), "c4": (256, 200000, 256)}[workload]
         n_hap, n_sites, n_states = args.haps or shape[0], args.sites or shape[1], shape[2]
@@ -399,6 +526,11 @@ def main() -> None:
 
     def step():
         """Decode this rank's shard; the path's only exchange: variable-length IBD records to rank 0."""
+        if args.mode == "sums":
+            plane, _ = ctx.decode_sums(model)
+            total = reduce_sums({"sumOverPairs": plane}, dist, rank, world, device=comm_device,
+                                force_collective=args.force_collective)
+            return (0, None) if total is None else (int(total["sumOverPairs"].shape[0]), total["sumOverPairs"])
         ctx.decode_ibd_launch(model, flags)
         rec = ctx.decode_ibd_fetch()
         return gather_ibd_records(rec, lo, dist, rank, world, device=comm_device,
@@ -449,6 +581,10 @@ def main() -> None:
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc,
+                       "mode": args.mode,
+                       **({"sums_checksum": float(np.asarray(merged, np.float64).sum()),
+                           "sums_reduction": "none" if dist is None else "rank order on rank 0"}
+                          if args.mode == "sums" and merged is not None else {}),
                        "pair_sites_per_s": value * pm.S, "ibd_records_per_step": n_rec,
                        "resident_waves": info["n_slots"], "n_cu": info["n_cu"],
                        "chunk_sites": info["chunk_sites"], "chunks_per_window": info["max_chunks"],
@@ -478,12 +614,13 @@ def main() -> None:
                 out["config"]["speedup_vs_n1"] = value / ref["value"]
         # the extra measurements ride on the DEFAULT line only: any option that shapes the workload or the plan makes
         # the run a measurement of its own
-        default_line = (world == 1 and args.workload == "auto" and not args.no_other_workloads
+        default_line = (world == 1 and args.workload == "auto" and args.mode == "ibd" and not args.no_other_workloads
                         and not args.diag_same_row and not args.haps and not args.sites and args.states == 69
                         and args.flags < 0 and not args.chunk_sites and not args.beta_stride
                         and args.resident_chunks < 0 and not args.force_collective)
         if default_line:
-            out["config"]["other_workloads"] = other_workloads(ctx, capi, flags, budget_s=60.0)
+            out["config"]["other_workloads"] = (c2_consumers(ctx, capi, model, pm, my_pairs)
+                                                + other_workloads(ctx, capi, flags, budget_s=120.0))
         if default_line and args.ws_frac:
             # the same step on the library's own workspace policy (no caller limit: a young context has earned
             # little): what FastSMC.run() gets in its first seconds

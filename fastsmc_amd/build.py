@@ -22,7 +22,7 @@ KT_MEMBERS = [16, 32, 48, 64, 69, 80, 96, 112, 128]
 # exact (ghost-free) members beside the 69-state one (csrc/fsmc_instances.h, FSMC_EXACT_KT): a model of exactly that many
 # states pays for no padding.  FSMC_EXACT_MEMBERS="50 100 75" in the environment of a build lists others (none a multiple
 # of 16, each <= 128 states); the list is part of the library's source hash.
-EXACT_MEMBERS = [int(x) for x in os.environ.get("FSMC_EXACT_MEMBERS", "50 100").split()]
+EXACT_MEMBERS = sorted(set(int(x) for x in os.environ.get("FSMC_EXACT_MEMBERS", "50 100").split()))  # (a member once)
 # wave-group kernel: (states per wave, waves per group) -- csrc/fsmc_instances.h, FSMC_ALL_W2
 W2_MEMBERS = [(48, 4), (64, 4), (80, 4), (64, 6), (64, 7), (64, 8)]
 

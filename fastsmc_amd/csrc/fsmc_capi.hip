@@ -68,6 +68,7 @@ struct fsmc_ctx {
   double wsEarned = 0; // bytes of workspace the launches so far (and the announced job) have paid for and not yet
                        // spent on an allocation (earnWorkspace, fsmc_ctx_expect_work, planLaunch)
   double wsAnnounced = 0; // estimated kernel seconds of announced work not launched yet (it has earned already)
+  double wsAnnouncedCredit = 0; // ... and the bytes of credit that part of the announcement was given
   std::string err;
 
   unsigned long long* dHaps = nullptr;
@@ -318,6 +319,18 @@ struct W2Member {
 };
 W2Member w2Member(int K)
 {
+  // (diagnostic: FSMC_DIAG_W2_MEMBER="<waves>x<states per wave>" picks another member that holds the model -- A/B runs)
+  if (const char* v = std::getenv("FSMC_DIAG_W2_MEMBER")) {
+    int nw = 0, kh = 0;
+    if (std::sscanf(v, "%dx%d", &nw, &kh) == 2 && nw * kh >= K) {
+#define FSMC_IS_W2(KHX, NWX)                                                                                            \
+  if (kh == KHX && nw == NWX) {                                                                                        \
+    return {nw, kh};                                                                                                   \
+  }
+      FSMC_ALL_W2(FSMC_IS_W2)
+#undef FSMC_IS_W2
+    }
+  }
   if (K <= 192) return {4, 48};
   if (K <= 256) return {4, 64};
   if (K <= 320) return {4, 80};
@@ -387,7 +400,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
     }
     const int NW = m->w2NW, KH = m->KP / NW;
     // 1048 ... 1112: four waves per group of 48 ... 112 states; 5064 ... 8064: five ... eight waves of 64
-    m->ctx->lastMember = NW == kW2NW ? 1000 + KH : 1000 * NW + KH;
+    m->ctx->lastMember = NW == kW2NW ? 1000 + KH : 1000 * NW + KH; // (2128: two waves of 128)
 #define FSMC_PICK_W2(KHX, NWX)                                                                                          \
   if (KH == KHX && NW == NWX) {                                                                                        \
     return pickWaveGroupKernel<KHX, NWX>(mode, track, m->sequence != 0);                                               \
@@ -521,6 +534,9 @@ void earnWorkspace(fsmc_ctx* ctx, const fsmc_model* m, int mode)
   double seconds = pairSites * (8.0 * m->K + 0.25) / (0.8 * 8e12);
   // (work that was announced has earned already: fsmc_ctx_expect_work)
   const double announced = std::min(ctx->wsAnnounced, seconds);
+  if (ctx->wsAnnounced > 0) {
+    ctx->wsAnnouncedCredit *= (ctx->wsAnnounced - announced) / ctx->wsAnnounced; // (that part is spent: it was launched)
+  }
   ctx->wsAnnounced -= announced;
   seconds -= announced;
   ctx->wsEarned += earnScale() * kEarnFraction * seconds * kAllocBytesPerSecond;
@@ -910,11 +926,24 @@ int fsmc_ctx_expect_work(fsmc_ctx* ctx, double pair_sites, int32_t states)
   if (!(pair_sites >= 0) || states < 1) {
     return fail(ctx, FSMC_EINVAL, "expected work: pair-sites >= 0 and states >= 1");
   }
+  if (pair_sites == 0) {
+    // the announced job is over (HMM::finishDecoding / finishFromHashing): what is left of the announcement -- an
+    // estimate that was too high, pairs that were filtered, a job that threw -- is forgotten and its unspent credit
+    // taken back, so that a later job on this context earns from its own launches again
+    ctx->wsEarned = std::max(0.0, ctx->wsEarned - ctx->wsAnnouncedCredit);
+    ctx->wsAnnounced = 0;
+    ctx->wsAnnouncedCredit = 0;
+    return FSMC_OK;
+  }
   // the job's launches will save what workspace upgrades save of its estimated kernel time: its credit is there at the
-  // first launch (workspaceBudget); the launches themselves then earn nothing until the announced work is used up
+  // first launch (workspaceBudget); the launches themselves then earn nothing until the announced work is used up.
+  // No announcement is worth more than the card: the credit is capped at the device's memory.
   const double seconds = pair_sites * (8.0 * states + 0.25) / (0.8 * 8e12);
+  const double credit = std::min(earnScale() * kEarnFraction * seconds * kAllocBytesPerSecond,
+                                 std::max(0.0, (double)ctx->hbmBytes - ctx->wsAnnouncedCredit));
   ctx->wsAnnounced += seconds;
-  ctx->wsEarned += earnScale() * kEarnFraction * seconds * kAllocBytesPerSecond;
+  ctx->wsAnnouncedCredit += credit;
+  ctx->wsEarned += credit;
   return FSMC_OK;
 }
 
@@ -1922,20 +1951,31 @@ int fsmc_decode_sums_batches(fsmc_ctx* ctx, const fsmc_model* m, const uint32_t*
   // continue the same sequential sum.
   const size_t plane = (size_t)m->S * m->K;
   const int nP = mm ? 4 : 1; // planes per group: the sum, or the sum and its 00 / 01 / 11 split
-  const uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.25 * (double)ctx->hbmBytes);
+  // what the planes may take: the caller's limit (or a quarter of the card) -- and no more than the card has left
+  // beside the workspace this context already holds
+  uint64_t limit = ctx->wsLimit ? ctx->wsLimit : (uint64_t)(0.25 * (double)ctx->hbmBytes);
+  {
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+      const uint64_t room = (uint64_t)freeB + ctx->out.bytes;
+      const uint64_t reserve = 2ull << 30;
+      limit = std::min<uint64_t>(limit, room > reserve ? room - reserve : 0);
+    }
+  }
+  const size_t slotFloats = (size_t)nP * plane; // a slot holds the planes the launch was asked for
   size_t slots = std::min<size_t>((size_t)plan.slots, n_batches);
-  slots = std::max<size_t>(1, std::min<size_t>(slots, limit / (4 * plane * sizeof(float))));
+  slots = std::max<size_t>(1, std::min<size_t>(slots, limit / (slotFloats * sizeof(float))));
   if (const char* cap = std::getenv("FSMC_DIAG_SUMS_SLOTS")) { // tests: force many launches on a small problem
     const long v = std::atol(cap);
     if (v >= 1 && (size_t)v < slots) {
       slots = (size_t)v;
     }
   }
-  rc = ensure(ctx, ctx->out, (slots + 1) * 4 * plane * sizeof(float));
+  rc = ensure(ctx, ctx->out, (slots + 1) * slotFloats * sizeof(float));
   if (rc != FSMC_OK) {
     return rc;
   }
-  float* const acc = (float*)ctx->out.p + slots * 4 * plane;
+  float* const acc = (float*)ctx->out.p + slots * slotFloats;
   float* dst[4] = {sums, sums00, sums01, sums11};
   for (int q = 0; q < 4; ++q) {
     if (dst[q]) {
@@ -1947,7 +1987,7 @@ int fsmc_decode_sums_batches(fsmc_ctx* ctx, const fsmc_model* m, const uint32_t*
   fillParams(ctx, m, plan, (sums ? FSMC_WANT_SUMS : 0u) | (mm ? FSMC_WANT_MAJOR_MINOR_SUMS : 0u), p);
   p.sums = (float*)ctx->out.p;
   p.sumsPlane = plane;
-  (void)nP;
+  p.sumsSlot = slotFloats;
   if (batch_first_group) {
     rc = ensure(ctx, ctx->aux, (n_batches + 1) * sizeof(uint32_t));
     if (rc != FSMC_OK) {
@@ -1966,7 +2006,7 @@ int fsmc_decode_sums_batches(fsmc_ctx* ctx, const fsmc_model* m, const uint32_t*
     }
     // (planes the launch did not ask for hold stale values: they are added to accumulator planes nobody reads)
     hipLaunchKernelGGL(add_planes_in_order_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const float*)ctx->out.p, acc,
-                       4 * plane, (int)n, 4 * plane);
+                       slotFloats, (int)n, slotFloats);
     FSMC_HIP(ctx, hipGetLastError());
   }
   FSMC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -89,7 +89,8 @@ struct KParams {
   const float* expCoal;       // kModePerPair: [KP]
   unsigned long long* phaseCycles; // diagnostic builds (-DFSMC_PHASE_STAMPS): [0] pass B, [1] rebuild, [2] alpha sweep, [3] groups
   float* sums;                // kModeSums: one plane [S][K] (x4 with the 00/01/11 sums) per wave of the launch
-  size_t sumsPlane;           // floats per plane per slot
+  size_t sumsPlane;           // floats per plane
+  size_t sumsSlot;            // floats per slot (wave / workgroup of the launch): one plane, or four with the 00/01/11 sums
   const unsigned* batchFirst; // kModeSums: [nBatches + 1] first group of every batch (null: every group is a batch)
   int residentChunks;         // chunked windows, array mode: the first this-many chunks of a window keep the rows pass B
                               // computes for them (a chunk buffer each) and skip the rebuild pass
@@ -1837,8 +1838,8 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
           for (int kb = 0; kb < Kreal; kb += 2 * kWave) {
             const int kk0 = kb + lane, kk1 = kb + kWave + lane;
             const bool h0 = kk0 < Kreal, h1 = kk1 < Kreal;
-            float* const acc0 = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + (h0 ? kk0 : 0);
-            float* const acc1 = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * Kreal + (h1 ? kk1 : 0);
+            float* const acc0 = p.sums + (size_t)blockIdx.x * p.sumsSlot + (size_t)pos * Kreal + (h0 ? kk0 : 0);
+            float* const acc1 = p.sums + (size_t)blockIdx.x * p.sumsSlot + (size_t)pos * Kreal + (h1 ? kk1 : 0);
             float s[2] = {0.f, 0.f}, s00[2] = {0.f, 0.f}, s01[2] = {0.f, 0.f}, s11[2] = {0.f, 0.f};
             if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
               if (p.flags & FSMC_WANT_SUMS) {

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kWave) void decode_kernel_any(const KParams p)
           __builtin_amdgcn_s_barrier();
           const float* pf = reinterpret_cast<const float*>(post);
           for (int kk = lane; kk < K; kk += kWave) {
-            float* a = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + kk;
+            float* a = p.sums + (size_t)blockIdx.x * p.sumsSlot + (size_t)pos * K + kk;
             float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
             if (round > 0) {
               if (p.flags & FSMC_WANT_SUMS) s = a[0];

@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
             const int kLocal = base + lane;
             const int state = h * KH + kLocal;
             if (kLocal < KH && state < K) {
-              float* acc = p.sums + (size_t)blockIdx.x * 4 * p.sumsPlane + (size_t)pos * K + state;
+              float* acc = p.sums + (size_t)blockIdx.x * p.sumsSlot + (size_t)pos * K + state;
               float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
               if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
                 if (p.flags & FSMC_WANT_SUMS) s = acc[0];

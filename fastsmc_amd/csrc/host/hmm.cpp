@@ -467,16 +467,52 @@ void HMM::closePerPairFiles()
   }
 }
 
+void HMM::updateOutputStructures()
+{
+  // (the reference resizes its per-batch mean / MAP buffers here; the device path has none)
+  resetDecoding(); // HMM.cpp:1757
+}
+
+void HMM::setStorePerPairPosteriorMean(bool v)
+{
+  flush(); // (what is queued was decoded under the old setting in the reference)
+  mStoreMean = v;
+  updateOutputStructures();
+}
+
+void HMM::setStorePerPairMap(bool v)
+{
+  flush(); // (what is queued was decoded under the old setting in the reference)
+  mStoreMap = v;
+  updateOutputStructures();
+}
+
+void HMM::setStorePerPairPosterior(bool v)
+{
+  flush(); // (what is queued was decoded under the old setting in the reference)
+  mStorePosterior = v;
+  updateOutputStructures();
+}
+
+void HMM::setStoreSumOfPosterior(bool v)
+{
+  flush(); // (what is queued was decoded under the old setting in the reference)
+  mStoreSumOfPosterior = v;
+  updateOutputStructures();
+}
+
 void HMM::setWritePerPairPosteriorMean(bool v)
 {
+  flush(); // (what is queued was decoded under the old setting in the reference)
   mWriteMean = v;
-  resetDecoding(); // (updateOutputStructures ends in resetDecoding, HMM.cpp:1757)
+  updateOutputStructures();
 }
 
 void HMM::setWritePerPairMap(bool v)
 {
+  flush(); // (what is queued was decoded under the old setting in the reference)
   mWriteMap = v;
-  resetDecoding();
+  updateOutputStructures();
 }
 
 void HMM::resetDecoding()
@@ -768,7 +804,9 @@ void HMM::flush()
       // continues that line.  Reproduced as it is (the files are the reference's, quirk included): a newline goes in
       // front of every row that is not the first of its batch.  FullPrecision for float is the stream at
       // NumTraits<float>::digits10() = 6 significant digits (Eigen 3.4, the version the reference's unpinned vcpkg
-      // dependency resolves to; general notation = "%.6g"); the MAP matrix is integer.
+      // dependency resolves to; general notation = "%.6g"); the MAP matrix is integer.  Eigen master / 5.x print
+      // max_digits10 = 9 there: FSMC_EIGEN_FULL_PRECISION_DIGITS=9 in the environment writes the file such a build of
+      // the reference writes.
       const auto B = static_cast<uint64_t>(mBatchSize);
       std::string text;
       char buf[48];
@@ -792,7 +830,17 @@ void HMM::flush()
         gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
       };
       if (mMeanFile) {
-        writeRows(mMeanFile, [&](char* b, size_t n, size_t idx) { return std::snprintf(b, n, "%.6g", static_cast<double>(mean[idx])); });
+        int digits = 6;
+        if (const char* v = std::getenv("FSMC_EIGEN_FULL_PRECISION_DIGITS")) {
+          const int d = std::atoi(v);
+          if (d != 6 && d != 9) {
+            throw std::runtime_error("FSMC_EIGEN_FULL_PRECISION_DIGITS is 6 (Eigen 3.4) or 9 (Eigen 5)");
+          }
+          digits = d;
+        }
+        writeRows(mMeanFile, [&](char* b, size_t n, size_t idx) {
+          return std::snprintf(b, n, "%.*g", digits, static_cast<double>(mean[idx]));
+        });
       }
       if (mMapFile) {
         writeRows(mMapFile, [&](char* b, size_t n, size_t idx) { return std::snprintf(b, n, "%d", map[idx]); });
@@ -858,14 +906,44 @@ void HMM::openIbdFile(int jobs, int jobInd)
     gzclose(mIbdFile);
     mIbdFile = nullptr;
   }
+  if (!mWriteIbdFile) {
+    return; // (records are kept and gathered: setWriteIbdFile)
+  }
   const std::string name = ibdFileName(jobs, jobInd);
   mIbdFile = gzopen(name.c_str(), mParams.BIN_OUT ? "wb" : "w");
   if (!mIbdFile) {
     throw std::runtime_error("cannot open IBD output file " + name);
   }
   if (mParams.BIN_OUT && mShardRank == 0) {
-    writeBinaryHeader();
+    writeBinaryHeader(mIbdFile);
   }
+}
+
+void HMM::writeIbdRecordsTo(const std::string& fileName, const std::vector<fsmc_pair>& pairs,
+                            const std::vector<fsmc_ibd_record>& records) const
+{
+  if (pairs.size() != records.size()) {
+    throw std::runtime_error("writeIbdRecordsTo: one pair per record");
+  }
+  const int S = static_cast<int>(mData.sites);
+  for (size_t i = 0; i < records.size(); ++i) {
+    const fsmc_ibd_record& r = records[i];
+    if (r.start < 0 || r.end < r.start || r.end >= S || pairs[i].hap_a >= 2 * mData.numIndividuals() ||
+        pairs[i].hap_b >= 2 * mData.numIndividuals()) {
+      throw std::runtime_error("writeIbdRecordsTo: record " + std::to_string(i) + " lies outside this data set");
+    }
+  }
+  gzFile file = gzopen(fileName.c_str(), mParams.BIN_OUT ? "wb" : "w");
+  if (!file) {
+    throw std::runtime_error("cannot open IBD output file " + fileName);
+  }
+  if (mParams.BIN_OUT) {
+    writeBinaryHeader(file);
+  }
+  for (size_t i = 0; i < records.size(); ++i) {
+    emitIbd(file, pairs[i], records[i]);
+  }
+  gzclose(file);
 }
 
 template <typename Fn> void HMM::forEachPairOfJob(int jobs, int jobInd, bool shardOnly, Fn&& fn) const
@@ -1001,6 +1079,9 @@ void HMM::finishDecoding()
 {
   closeBatch(true);
   flush();
+  if (mCtx) { // the announced job (decodeAll, the hashing driver) is over: no phantom work stays behind
+    fsmc_ctx_expect_work(mCtx, 0.0, static_cast<int32_t>(mDq.states));
+  }
   closePerPairFiles(); // HMM.cpp:518-523
   if (!(mParams.FastSMC && mParams.hashing)) {
     std::fill(mFromBatch.begin(), mFromBatch.end(), 0u);
@@ -1012,6 +1093,9 @@ void HMM::finishFromHashing()
 {
   closeBatch(true);
   flush();
+  if (mCtx) {
+    fsmc_ctx_expect_work(mCtx, 0.0, static_cast<int32_t>(mDq.states));
+  }
   closeIBDFile();
   if (std::getenv("FSMC_HOST_TIMING")) {
     std::fprintf(stderr, "[fsmc host] work-list upload %.3f s, decode (launch + fetch) %.3f s, records out %.3f s\n",
@@ -1065,9 +1149,14 @@ void HMM::writeIbd(const fsmc_pair& pr, const fsmc_ibd_record& r)
   if (!mIbdFile) {
     return;
   }
+  emitIbd(mIbdFile, pr, r);
+}
+
+void HMM::emitIbd(gzFile file, const fsmc_pair& pr, const fsmc_ibd_record& r) const
+{
   if (!mParams.BIN_OUT) {
     const std::string s = formatIbdRecord(pr, r);
-    gzwrite(mIbdFile, s.c_str(), static_cast<unsigned>(s.size()));
+    gzwrite(file, s.c_str(), static_cast<unsigned>(s.size()));
     return;
   }
   const auto [iInd, iHap] = hapToDipId(pr.hap_a);
@@ -1077,40 +1166,40 @@ void HMM::writeIbd(const fsmc_pair& pr, const fsmc_ibd_record& r)
   const int pos[2] = {mData.physicalPositions[r.start], mData.physicalPositions[r.end]};
   const float ibd_score =
       static_cast<float>(r.prob / static_cast<double>(static_cast<unsigned>(r.end - r.start) + 1u));
-  gzwrite(mIbdFile, &ind[0], sizeof(unsigned int));
-  gzwrite(mIbdFile, &hap[0], sizeof(std::uint_least8_t));
-  gzwrite(mIbdFile, &ind[1], sizeof(unsigned int));
-  gzwrite(mIbdFile, &hap[1], sizeof(std::uint_least8_t));
-  gzwrite(mIbdFile, &pos[0], sizeof(int));
-  gzwrite(mIbdFile, &pos[1], sizeof(int));
+  gzwrite(file, &ind[0], sizeof(unsigned int));
+  gzwrite(file, &hap[0], sizeof(std::uint_least8_t));
+  gzwrite(file, &ind[1], sizeof(unsigned int));
+  gzwrite(file, &hap[1], sizeof(std::uint_least8_t));
+  gzwrite(file, &pos[0], sizeof(int));
+  gzwrite(file, &pos[1], sizeof(int));
   if (mParams.outputIbdSegmentLength) {
     const float length_cM = 100.f * (mData.geneticPositions[r.end] - mData.geneticPositions[r.start]);
-    gzwrite(mIbdFile, &length_cM, sizeof(float));
+    gzwrite(file, &length_cM, sizeof(float));
   }
-  gzwrite(mIbdFile, &ibd_score, sizeof(float));
+  gzwrite(file, &ibd_score, sizeof(float));
   if (mParams.doPerPairPosteriorMean) {
-    gzwrite(mIbdFile, &r.post_mean, sizeof(float));
+    gzwrite(file, &r.post_mean, sizeof(float));
   }
   if (mParams.doPerPairMAP) {
-    gzwrite(mIbdFile, &r.map, sizeof(float));
+    gzwrite(file, &r.map, sizeof(float));
   }
 }
 
-void HMM::writeBinaryHeader()
+void HMM::writeBinaryHeader(gzFile file) const
 {
-  gzwrite(mIbdFile, &mParams.outputIbdSegmentLength, sizeof(bool));
-  gzwrite(mIbdFile, &mParams.doPerPairPosteriorMean, sizeof(bool));
-  gzwrite(mIbdFile, &mParams.doPerPairMAP, sizeof(bool));
-  gzwrite(mIbdFile, &mData.chrNumber, sizeof(int));
+  gzwrite(file, &mParams.outputIbdSegmentLength, sizeof(bool));
+  gzwrite(file, &mParams.doPerPairPosteriorMean, sizeof(bool));
+  gzwrite(file, &mParams.doPerPairMAP, sizeof(bool));
+  gzwrite(file, &mData.chrNumber, sizeof(int));
   const unsigned int nbInd = static_cast<unsigned>(mData.numIndividuals());
-  gzwrite(mIbdFile, &nbInd, sizeof(unsigned int));
+  gzwrite(file, &nbInd, sizeof(unsigned int));
   for (unsigned i = 0; i < nbInd; i++) {
     const unsigned lengthFamid = static_cast<unsigned>(mData.FamIDList[i].size());
-    gzwrite(mIbdFile, &lengthFamid, sizeof(unsigned int));
-    gzwrite(mIbdFile, mData.FamIDList[i].c_str(), lengthFamid);
+    gzwrite(file, &lengthFamid, sizeof(unsigned int));
+    gzwrite(file, mData.FamIDList[i].c_str(), lengthFamid);
     const unsigned lengthIid = static_cast<unsigned>(mData.IIDList[i].size());
-    gzwrite(mIbdFile, &lengthIid, sizeof(unsigned int));
-    gzwrite(mIbdFile, mData.IIDList[i].c_str(), lengthIid);
+    gzwrite(file, &lengthIid, sizeof(unsigned int));
+    gzwrite(file, mData.IIDList[i].c_str(), lengthIid);
   }
 }
 

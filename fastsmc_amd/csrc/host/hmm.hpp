@@ -124,10 +124,13 @@ public:
   // (TESTS/test_HMM.cpp:49-79)
   std::vector<PairObservations> getBatchBuffer() const;
 
-  void setStorePerPairPosteriorMean(bool v) { mStoreMean = v; }
-  void setStorePerPairMap(bool v) { mStoreMap = v; }
-  void setStorePerPairPosterior(bool v) { mStorePosterior = v; }
-  void setStoreSumOfPosterior(bool v) { mStoreSumOfPosterior = v; }
+  // Every setStore* / setWrite* setter ends in updateOutputStructures() -> resetDecoding() as in the reference
+  // (HMM.cpp:1733-1757, 1759-1800): the posterior sums are zeroed and the per-pair files reopened (truncated).  Full
+  // batches the reference would have decoded by then are decoded first (flush).
+  void setStorePerPairPosteriorMean(bool v);
+  void setStorePerPairMap(bool v);
+  void setStorePerPairPosterior(bool v);
+  void setStoreSumOfPosterior(bool v);
   // HMM.hpp:287,293: per-pair posterior means / MAP states of every decoded pair as text, one row per pair, to
   // <outFileRoot>.perPairPosteriorMeans.gz / .perPairMAP.gz (ASMC mode; opened by resetDecoding, HMM.cpp:259-271,
   // written batch by batch, HMM.cpp:1412-1420, closed by finishDecoding, HMM.cpp:515-524)
@@ -135,6 +138,7 @@ public:
   void setWritePerPairPosteriorMean(bool v = true);
   void setWritePerPairMap(bool v = true);
   void resetDecoding(); // HMM.cpp:258-280
+  void updateOutputStructures(); // HMM.cpp:1733-1757
 
   // Multi-GPU: this process decodes shard `rank` of `world` -- a contiguous range of the job's batches (whole
   // batches, so batch windows are those of a single-device run).  Output goes to "<file>.part<rank>of<world>";
@@ -152,8 +156,15 @@ public:
   // tell the engine how many pair-sites the coming flushes will decode (fsmc_ctx_expect_work: workspace policy)
   void announceWork(double pairSites);
 
-  // keep emitted IBD records in memory as well (tests, benchmarks)
+  // keep emitted IBD records in memory as well (tests, benchmarks, the multi-GPU gather)
   void setKeepIbdRecords(bool v) { mKeepRecords = v; }
+  // false: decodeAll / the hashing driver open no IBD file -- the records are only kept (setKeepIbdRecords) and leave
+  // the process through the record gather (multi-GPU runs whose ranks send their records to rank 0 over RCCL)
+  void setWriteIbdFile(bool v) { mWriteIbdFile = v; }
+  // the file a single-device run of this job would have written, from records gathered in output order (rank 0 of a
+  // multi-GPU run): header (binary output) and every record through the same formatter as writeIbd
+  void writeIbdRecordsTo(const std::string& fileName, const std::vector<fsmc_pair>& pairs,
+                         const std::vector<fsmc_ibd_record>& records) const;
   const std::vector<fsmc_ibd_record>& getIbdRecords() const { return mKeptRecords; }
   const std::vector<fsmc_pair>& getIbdRecordPairs() const { return mKeptPairs; }
   // ordinal of every kept record's pair among all the pairs this HMM has decoded (the candidate number in hashing mode)
@@ -173,7 +184,8 @@ private:
   void closeBatch(bool last);
   void flush();
   void writeIbd(const fsmc_pair& pr, const fsmc_ibd_record& r);
-  void writeBinaryHeader(); // HMM.cpp:383-401
+  void emitIbd(gzFile file, const fsmc_pair& pr, const fsmc_ibd_record& r) const;
+  void writeBinaryHeader(gzFile file) const; // HMM.cpp:383-401
   void openIbdFile(int jobs, int jobInd);
 
   Data mData;
@@ -211,6 +223,7 @@ private:
   uint64_t mPerPairRows = 0; // rows written to the per-pair files since they were opened (batch boundaries)
   void closePerPairFiles();
   bool mKeepRecords = false;
+  bool mWriteIbdFile = true;
   std::vector<fsmc_ibd_record> mKeptRecords;
   std::vector<fsmc_pair> mKeptPairs;
   std::vector<uint64_t> mKeptOrdinals;

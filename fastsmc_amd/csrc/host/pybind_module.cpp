@@ -400,6 +400,39 @@ PYBIND11_MODULE(_pyasmc, m)
              }
              return out;
            })
+      .def("setWriteIbdFile", &HMM::setWriteIbdFile, "write"_a,
+           "False: open no IBD file, only keep the records (setKeepIbdRecords) -- multi-GPU ranks whose records are gathered")
+      .def("writeIbdRecordArrays",
+           [](const HMM& h, const std::string& fileName, py::array_t<uint32_t, py::array::c_style | py::array::forcecast> ha,
+              py::array_t<uint32_t, py::array::c_style | py::array::forcecast> hb,
+              py::array_t<int32_t, py::array::c_style | py::array::forcecast> st,
+              py::array_t<int32_t, py::array::c_style | py::array::forcecast> en,
+              py::array_t<float, py::array::c_style | py::array::forcecast> pr,
+              py::array_t<float, py::array::c_style | py::array::forcecast> pm,
+              py::array_t<float, py::array::c_style | py::array::forcecast> mp) {
+             // the IBD file of records given as columns (those of getIbdRecordArrays, e.g. gathered from several ranks)
+             const size_t n = static_cast<size_t>(ha.size());
+             for (const py::ssize_t other : {hb.size(), st.size(), en.size(), pr.size(), pm.size(), mp.size()}) {
+               if (static_cast<size_t>(other) != n) {
+                 throw std::runtime_error("writeIbdRecordArrays: columns of different lengths");
+               }
+             }
+             std::vector<fsmc_pair> pairs(n);
+             std::vector<fsmc_ibd_record> recs(n);
+             for (size_t i = 0; i < n; ++i) {
+               const py::ssize_t k = static_cast<py::ssize_t>(i);
+               pairs[i].hap_a = ha.at(k);
+               pairs[i].hap_b = hb.at(k);
+               recs[i].pair = static_cast<uint32_t>(i);
+               recs[i].start = st.at(k);
+               recs[i].end = en.at(k);
+               recs[i].prob = pr.at(k);
+               recs[i].post_mean = pm.at(k);
+               recs[i].map = mp.at(k);
+             }
+             h.writeIbdRecordsTo(fileName, pairs, recs);
+           },
+           "fileName"_a, "hap_a"_a, "hap_b"_a, "start"_a, "end"_a, "prob"_a, "post_mean"_a, "map"_a)
       .def("getIbdRecordArrays",
            [](const HMM& h) {
              // the kept records as columns (numpy): pair ordinal, hapA, hapB, start, end, prob, postMean, map

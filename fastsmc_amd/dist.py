@@ -1,6 +1,7 @@
 """Multi-GPU plumbing for the decode path: one process per GPU (``torch.distributed``; backend "nccl" is
 RCCL on ROCm, "gloo" in CPU tests).  Pairs are independent, so the pair list is sharded with no collective
-on the data path; the only exchange is the final gather of variable-length IBD records to rank 0."""
+on the data path; the only exchanges are the final gather of variable-length IBD records to rank 0 (FastSMC mode)
+and the reduction of the per-rank posterior sums (ASMC mode, ``reduce_sums``)."""
 from __future__ import annotations
 
 import numpy as np
@@ -106,40 +107,78 @@ def gather_ibd_records(rec: np.ndarray, pair_offset: int, dist, rank: int, world
 
 
 def run_fastsmc_sharded(params, rank: int | None = None, world: int | None = None, local_rank: int | None = None,
-                        barrier=None) -> str | None:
+                        barrier=None, gather: str = "auto", force_collective: bool = False) -> str | None:
     """FastSMC.run() of one job spread over ``world`` GPUs, one process each (launch with
     ``python -m torch.distributed.run --nproc-per-node N ...`` or pass rank/world explicitly).  Every rank loads
-    the same inputs, decodes a contiguous range of the job's batches on device ``local_rank`` and writes
-    ``<output>.part<rank>of<world>``; after a barrier rank 0 concatenates the parts in rank order -- gzip members
-    concatenate into a valid stream whose content is byte-identical to the single-GPU output -- and removes them.
-    No collective on the data path.  Returns the output file name on rank 0, None elsewhere."""
+    the same inputs and decodes a contiguous range of the job's batches on device ``local_rank``; no collective on the
+    data path.  How the records reach the one output file:
+
+    * ``gather="records"`` -- the path's one exchange over the process group: every rank keeps its records in memory
+      (no part file), ``gather_hmm_records`` sends them to rank 0 -- RCCL over xGMI when the group's backend is "nccl"
+      (payloads staged on ``cuda:local_rank``), gloo otherwise -- and rank 0 writes the file through the product's own
+      formatter (``HMM.writeIbdRecordArrays``): the bytes a single-GPU run decompresses to.
+    * ``gather="files"`` -- every rank writes ``<output>.part<rank>of<world>``; after a barrier rank 0 concatenates the
+      parts in rank order (gzip members concatenate into a valid stream whose content is byte-identical to the
+      single-GPU output) and removes them.  Needs a file system the ranks share; the fallback when there is no
+      process group to send records through (an explicit ``barrier`` callable).
+    * ``gather="auto"`` (default): "records" when ``torch.distributed`` is initialised (or is brought up here), "files"
+      when the caller passed its own ``barrier``.
+
+    An initialised process group is used as it is (backend "nccl" = RCCL: bring it up BEFORE the first other GPU call
+    of the process, tests/test_gpu_rccl_one_rank.py); without one, and without ``barrier``, a gloo group is brought up
+    here.  ``force_collective``: a world of ONE rank takes the "records" route all the same, through the initialised
+    group's collectives (the one-rank rehearsal of the RCCL leg on a one-GPU box).  Returns the output file name on
+    rank 0, None elsewhere."""
     import os
     import shutil
 
     from . import api
 
+    if gather not in ("auto", "records", "files"):
+        raise ValueError("gather is 'auto', 'records' or 'files'")
     rank = int(os.environ.get("RANK", 0)) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
     local_rank = int(os.environ.get("LOCAL_RANK", rank)) if local_rank is None else local_rank
-    if barrier is None and world > 1:
+    dist = None
+    if (world > 1 or force_collective) and (barrier is None or gather == "records"):
         import torch.distributed as dist
 
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only
-        barrier = dist.barrier
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if barrier is None:
+            barrier = dist.barrier
+    if gather == "auto":
+        gather = "records" if dist is not None else "files"
     params.gpuDevice = local_rank
     f = api.FastSMC(params)
     f.setShard(rank, world)
     part = f.outputFileName()
-    f.run()
-    if world == 1:
+    if world == 1 and not force_collective:
+        f.run()
         return part
+    final = part[: part.rindex(".part")] if ".part" in part else part
+    if gather == "records":
+        device = "cpu"
+        if dist.get_backend() == "nccl":
+            import torch
+
+            torch.cuda.set_device(local_rank)
+            device = "cuda"
+        hmm = f.hmm()
+        hmm.setKeepIbdRecords(True)
+        hmm.setWriteIbdFile(False)
+        f.run()
+        _, rows = gather_hmm_records(hmm, dist, rank, world, device=device, force_collective=force_collective)
+        if rank == 0:
+            hmm.writeIbdRecordArrays(final, rows["hap_a"], rows["hap_b"], rows["start"], rows["end"], rows["prob"],
+                                     rows["post_mean"], rows["map"])
+        barrier()
+        return final if rank == 0 else None
+    f.run()
     barrier()
-    final = None
     if rank == 0:
-        final = part[: part.rindex(".part")]
         with open(final, "wb") as out:
             for r in range(world):
                 name = f"{final}.part{r}of{world}"
@@ -147,7 +186,7 @@ def run_fastsmc_sharded(params, rank: int | None = None, world: int | None = Non
                     shutil.copyfileobj(src, out)
                 os.remove(name)
     barrier()
-    return final
+    return final if rank == 0 else None
 
 
 IBD_COLUMNS = (("pair", np.uint64), ("hap_a", np.uint32), ("hap_b", np.uint32), ("start", np.int32), ("end", np.int32),
@@ -171,3 +210,81 @@ def gather_hmm_records(hmm, dist=None, rank: int = 0, world: int = 1, device="cp
     if dist is None or (world == 1 and not force_collective):
         return int(local.size), local
     return _gather_records(local, dist, rank, world, device)
+
+
+SUM_PLANES = ("sumOverPairs", "sumOverPairs00", "sumOverPairs01", "sumOverPairs11")
+
+
+def _sum_planes(source) -> dict:
+    """The posterior-sum planes a rank holds, as float32 [sites][states] arrays: an HMM (its DecodingReturnValues), a
+    DecodingReturnValues, or a mapping / sequence of arrays.  Planes the decode did not ask for are absent (empty)."""
+    if hasattr(source, "getDecodingReturnValues"):
+        source = source.getDecodingReturnValues()
+    if isinstance(source, dict):
+        items = list(source.items())
+    elif isinstance(source, (list, tuple)):
+        items = list(zip(SUM_PLANES, source))
+    else:
+        items = [(n, getattr(source, n)) for n in SUM_PLANES]
+    out = {}
+    for name, a in items:
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        if a.size:
+            out[name] = a
+    return out
+
+
+def reduce_sums(source, dist=None, rank: int = 0, world: int = 1, device="cpu", order: str = "rank",
+                force_collective: bool = False):
+    """Sum-over-pairs mode across ranks (ASMC mode: ``HMM.decodeAll(jobs, jobInd)`` with jobs = world, jobInd = rank + 1
+    -- the reference's own decomposition of a decode into jobs, HMM.cpp:310-321 -- leaves every rank the posterior sums
+    of ITS pairs, HMM.cpp:1044-1085).  The reference merges the jobs' matrices afterwards, job after job, in fp32
+    (TOOLS/MERGE_POSTERIORS PosteriorMerger.java:121-204: ``sum[r][c] += job's value`` in job order); this is that merge
+    over the process group:
+
+    * ``order="rank"`` (default): every rank's planes are gathered to rank 0 (one ``gather`` of the stacked planes: RCCL
+      over xGMI with backend "nccl" and ``device="cuda"``, gloo in CPU tests) and added there ONE RANK AFTER THE OTHER,
+      starting from zeros -- ``((0 + P_0) + P_1) + ...``, the reference's merge order, the way the library adds a
+      launch's batch planes to its accumulator (``add_planes_in_order_kernel``): the result is the same bits whatever
+      the transport.  Against ONE process that decodes all the pairs the sums differ by fp32 re-association at the
+      shard joins only: each rank's partial is the exact sequential sum of its batches, so the difference is bounded by
+      (world - 1) roundings of the running total per entry -- relative 6e-8 x (world - 1), tests use 1e-6.  Returns a
+      dict {plane name: [sites][states] float32} on rank 0, None on the other ranks.
+    * ``order="allreduce"``: one ``all_reduce(SUM)`` -- every rank gets the total, but the order of the additions is the
+      collective's (ring / tree): RE-ASSOCIATING, not reproducible bit for bit across world sizes or transports.
+
+    A group of one rank returns its own planes without a collective unless ``force_collective`` (the one-rank rehearsal
+    of the RCCL leg)."""
+    if order not in ("rank", "allreduce"):
+        raise ValueError("order is 'rank' or 'allreduce'")
+    planes = _sum_planes(source)
+    names = [n for n in SUM_PLANES if n in planes] + sorted(n for n in planes if n not in SUM_PLANES)
+    if dist is None or (world == 1 and not force_collective):
+        return {n: planes[n].copy() for n in names}
+    import torch
+
+    shapes = {planes[n].shape for n in names}
+    if len(shapes) > 1:
+        raise ValueError(f"planes of different shapes: {shapes}")
+    # every rank must bring the same planes (a rank whose shard is empty still holds zero-filled matrices)
+    have = torch.tensor([sum(1 << i for i, n in enumerate(SUM_PLANES) if n in planes), len(names)], device=device,
+                        dtype=torch.int64)
+    every = [torch.zeros_like(have) for _ in range(world)]
+    dist.all_gather(every, have)
+    if any(not torch.equal(e.cpu(), have.cpu()) for e in every):
+        raise ValueError("the ranks hold different posterior-sum planes")
+    if not names:
+        return {} if (rank == 0 or order == "allreduce") else None
+    stack = torch.from_numpy(np.stack([planes[n] for n in names])).to(device)
+    if order == "allreduce":
+        dist.all_reduce(stack)  # (SUM)
+        total = stack.cpu().numpy()
+        return {n: total[i] for i, n in enumerate(names)}
+    bucket = [torch.empty_like(stack) for _ in range(world)] if rank == 0 else None
+    dist.gather(stack, bucket, dst=0)
+    if rank != 0:
+        return None
+    acc = np.zeros(stack.shape, np.float32)
+    for r in range(world):  # rank order = job order = the reference's merge order
+        acc = acc + bucket[r].cpu().numpy()
+    return {n: acc[i] for i, n in enumerate(names)}

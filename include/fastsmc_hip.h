@@ -135,7 +135,10 @@ int fsmc_ctx_set_workspace_limit(fsmc_ctx* ctx, uint64_t bytes);
  * windows) of a model of `states` states: what the reference's HMM::decodeAll knows when it starts (its job's pair
  * range, HMM.cpp:310-321).  Under the library's own workspace policy (no limit set) the credit of the whole job is
  * then there at the first launch: a job long enough to pay for the card allocates it once, at its start, instead of
- * growing into it; a short job stays small.  The announced launches earn nothing again.  No effect with a limit set. */
+ * growing into it; a short job stays small.  The announced launches earn nothing again.  No effect with a limit set.
+ * pair_sites = 0 ends the announced job (HMM::finishDecoding, HMM.cpp:515-524): what is left of the announcement -- an
+ * estimate that was too high, a job that stopped early -- is forgotten and its unspent credit taken back.  The credit
+ * of announcements is capped at the device's memory. */
 int fsmc_ctx_expect_work(fsmc_ctx* ctx, double pair_sites, int32_t states);
 /* Tuning: sites between beta checkpoints when a decode window does not fit the workspace (0 = automatic:
  * max(512, ceil(sqrt(window))), 2048 for the wave-group kernel, rounded up to 16).  Results do not depend on it. */

@@ -16,6 +16,11 @@ def wave_group_member(K):
     """(waves per group, states per wave) of the wave-group kernel for a model of 128 < K <= 512 states, as
     fsmc_model_create picks it (csrc/fsmc_capi.hip, w2Member): four waves of 48 / 64 / 80 states, then six, seven, eight
     waves of 64."""
+    forced = os.environ.get("FSMC_DIAG_W2_MEMBER")  # (A/B runs of another member: the library honours the same variable)
+    if forced:
+        nw, kh = (int(x) for x in forced.split("x"))
+        if nw * kh >= K:
+            return (nw, kh)
     return ((4, 48) if K <= 192 else (4, 64) if K <= 256 else (4, 80) if K <= 320 else (6, 64) if K <= 384
             else (7, 64) if K <= 448 else (8, 64))
 

@@ -130,3 +130,70 @@ print("HMM_RECORDS_OK", n0)
                        cwd=ROOT, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "HMM_RECORDS_OK" in r.stdout
+
+
+def test_posterior_sums_through_rccl(tmp_path):
+    """Sum-over-pairs mode: the merge of the per-rank planes (`fastsmc_amd.dist.reduce_sums`, a gather to rank 0 and the
+    rank-ordered fp32 addition) with the collective forced through RCCL on one rank -- `0 + P_0` is `P_0`: the plane of
+    the plain run, bit for bit -- and the re-associating all-reduce variant on the same communicator."""
+    shape = ["--mode", "sums", "--workload", "c1", "--haps", "64", "--sites", "400", "--steps", "1", "--warmup", "1",
+             "--cpu-pairs", "0"]
+    outs = []
+    for extra, name in (([], "plain.npy"), (["--force-collective"], "rccl.npy")):
+        path = str(tmp_path / name)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *shape, *extra,
+                            "--dump-records", path], capture_output=True, text=True, env=_env(), cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        assert line["config"]["mode"] == "sums"
+        assert line["config"]["sums_reduction"] == ("rank order on rank 0" if extra else "none")
+        outs.append(np.load(path))
+    assert outs[0].shape == (400, 69) and outs[0].any() and np.array_equal(outs[0], outs[1])
+    child = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from fastsmc_amd.dist import reduce_sums
+rng = np.random.default_rng(3)
+planes = {n: rng.random((50, 12), dtype=np.float32) for n in ("sumOverPairs", "sumOverPairs00", "sumOverPairs01", "sumOverPairs11")}
+for order in ("rank", "allreduce"):
+    got = reduce_sums(planes, dist, 0, 1, device="cuda", order=order, force_collective=True)
+    assert list(got) == list(planes) and all(np.array_equal(got[n], planes[n]) for n in planes), order
+dist.destroy_process_group()
+print("SUMS_RCCL_OK", "|".join(sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})))
+"""
+    r = subprocess.run([sys.executable, "-c", child, ROOT], capture_output=True, text=True, env=_env(), cwd=ROOT,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "SUMS_RCCL_OK" in r.stdout and "librccl" in r.stdout
+
+
+def test_product_driver_gathers_its_records_through_rccl(tmp_path):
+    """`run_fastsmc_sharded` on an initialised "nccl" group (one rank, collective forced): no part file, the records
+    travel through RCCL from `cuda:0` and rank 0 writes the file -- the bytes of a plain FastSMC.run()."""
+    child = r"""
+import gzip, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from fastsmc_amd import api
+from fastsmc_amd import dist as fd
+from test_gpu_api import _params, make_files
+files = make_files(sys.argv[2])
+for kw in (dict(), dict(BIN_OUT=True), dict(hashing=True, min_m=1.0)):
+    f = api.FastSMC(_params(files, os.path.join(sys.argv[2], "plain"), **kw))
+    f.run()
+    want = gzip.open(f.outputFileName(), "rb").read()
+    out = fd.run_fastsmc_sharded(_params(files, os.path.join(sys.argv[2], "rccl"), **kw), rank=0, world=1, local_rank=0,
+                                 gather="records", force_collective=True)
+    assert len(want) > 1000 and gzip.open(out, "rb").read() == want, kw
+dist.destroy_process_group()
+print("DRIVER_RCCL_OK", "|".join(sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})))
+"""
+    r = subprocess.run([sys.executable, "-c", child, ROOT, str(tmp_path)], capture_output=True, text=True, env=_env(),
+                       cwd=ROOT, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "DRIVER_RCCL_OK" in r.stdout and "librccl" in r.stdout

@@ -119,6 +119,14 @@ def test_an_announced_job_has_its_workspace_at_the_first_launch(small_problem, m
         ctx.close()
     assert out[0.0][0] == 0 and out[1e15][0] == out[1e15][1] > 10
     assert out[0.0][2] == out[1e15][2]
+    # the announced job ends before it launches (pair_sites = 0: HMM::finishDecoding): the unspent credit is taken back
+    # and nothing of the announcement stays behind -- the next launch is a young context's again
+    ctx, model = _ctx(small_problem, 2, limit=0, chunk=48)
+    ctx.expect_work(1e15, small_problem["model"].K)
+    ctx.expect_work(0.0, small_problem["model"].K)
+    rec = ctx.decode_ibd(model, _pairs_array(pairs), groups, flags)
+    assert ctx.last_resident_chunks() == 0 and rec.tobytes() == out[0.0][2]
+    ctx.close()
     ctx, _ = _ctx(small_problem, 2, limit=0, chunk=48)
     with pytest.raises(capi.FsmcError):
         ctx.expect_work(-1.0, 69)

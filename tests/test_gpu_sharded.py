@@ -81,3 +81,32 @@ def test_in_memory_records_of_the_shards_are_the_single_device_stream(files, tmp
         if name != "pair":  # (ordinals count from the start of each rank's shard)
             np.testing.assert_array_equal(merged[name], one[name], err_msg=name)
     assert all((np.diff(p["pair"].astype(np.int64)) >= 0).all() for p in parts)
+
+
+def _worker_kw(rank, world, port, files, out, kw, gather):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.run_fastsmc_sharded(_params(files, out, **kw), rank=rank, world=world, local_rank=0, gather=gather)
+
+
+@pytest.mark.parametrize("gather", ["records", "files"])
+@pytest.mark.parametrize("kw", [dict(BIN_OUT=True), dict()], ids=["binary", "text"])
+def test_sharded_two_processes_both_routes(files, tmp_path, kw, gather):
+    """Two processes on the one card with a gloo group: the records gathered over the process group and written by rank
+    0 (`gather="records"`, the route an RCCL group takes too) and the part files (`gather="files"`) both decompress to
+    the single-device output, text and binary (header once)."""
+    want = _single(files, str(tmp_path / "one"), **kw)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "two")
+    procs = [ctx.Process(target=_worker_kw, args=(r, 2, port, files, out, kw, gather)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+        assert pr.exitcode == 0
+    name = out + (".1.1.FastSMC.bibd.gz" if kw.get("BIN_OUT") else ".1.1.FastSMC.ibd.gz")
+    assert gzip.open(name, "rb").read() == want
+    assert not [n for n in os.listdir(tmp_path) if ".part" in n]

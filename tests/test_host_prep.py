@@ -227,6 +227,35 @@ def test_expected_coal_times_file_is_read_like_the_reference(tmp_path):
     api.HMM(data, dq, p)  # FastSMC mode does not look at it
 
 
+def test_expected_coal_times_from_the_reference_intervals_file():
+    """The reference's own input of `expectedCoalTimesFile` -- FILES/DECODING_QUANTITIES/30-100-2000.intervalsInfo, 69
+    lines "intervalStart <tab> expectedCoalescentTime <tab> intervalEnd", committed as tests/golden/30-100-2000.intervalsInfo
+    -- read through the product's reader (HMM.cpp:43-61): the 69 values are the second column, each parsed as the
+    reference's StringUtils::stof does (stold, then one rounding to float: StringUtils.cpp:36-39), they lie inside their
+    intervals, and an ASMC-mode HMM of a 69-state model hands them out as its expected coalescence times."""
+    import numpy as np
+    from fastsmc_amd import api, synth
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "30-100-2000.intervalsInfo")
+    rows = [ln.split() for ln in open(path)]
+    assert len(rows) == 69 and all(len(r) == 3 for r in rows)
+    want = np.array([np.float32(np.longdouble(r[1])) for r in rows], np.float32)
+    starts = np.array([float(r[0]) for r in rows])
+    ends = np.array([float(r[2]) for r in rows])  # (the last interval ends at "Infinity")
+    assert starts[0] == 0.0 and np.array_equal(starts[1:], ends[:-1]) and np.isinf(ends[-1])
+    assert np.all(want > starts) and np.all(want[:-1] < ends[:-1])
+    tables = synth.make_model_tables(69)
+    haps = synth.make_haps(64, 60, seed=3)
+    data = api.Data.from_arrays(haps.alleles, haps.bp, haps.cm, True, True)
+    dq = api.decoding_quantities_from_tables(tables)
+    p = api.DecodingParams()
+    p.FastSMC = False
+    p.expectedCoalTimesFile = path
+    got = np.array(api.HMM(data, dq, p).getExpectedCoalTimes(), np.float32)
+    np.testing.assert_array_equal(got, want)
+    assert not np.array_equal(got, np.asarray(tables.expected_times, np.float32))  # (the file's, not the model's)
+
+
 def test_bench_unpacks_the_folded_alleles_it_gives_the_cpu_baseline():
     """bench.py's cpu_baseline decodes the first pairs of the GPU's own work list on the host: the folded alleles it
     hands the oracle come out of the packed matrix the GPU decodes from (`folded_rows_from_bits`) -- they must be the

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -233,3 +234,102 @@ def test_bench_start_up_of_two_ranks_builds_the_cohort_once(tmp_path):
         assert 0 < line["pairs_of_rank_0"] < 1500  # its shard of the one list
         cores = len(os.sched_getaffinity(0))
         assert line["host_threads_per_rank"] == str(max(1, cores // 2))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sum-over-pairs mode across ranks (fastsmc_amd.dist.reduce_sums): the reference's jobs + PosteriorMerger, world 2 / 3
+
+def _sums_problem():
+    from fastsmc_amd import synth
+    from oracle import oracle as O
+
+    tables = synth.make_model_tables(12)
+    haps = synth.make_haps(64, 48, seed=13, cm_per_mb=25.0, switch_per_cm=0.6)  # (16 of its 32 individuals are decoded)
+    _, derived, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    pm = O.prepare_model(tables, (haps.cm / 100.0).astype(np.float32), haps.bp, derived, 64, time=50)
+    return pm, folded
+
+
+def _job_sums(pm, folded, jobs, job_ind, batch=64):
+    """The four posterior-sum planes HMM::decodeAll(jobs, jobInd) leaves (HMM.cpp:310-357, 1044-1085), by the oracle:
+    the job's pairs in enumeration order, batches of `batch`, every batch's local sum added to the planes in turn."""
+    from oracle import oracle as O
+
+    pairs = O.enumerate_all_pairs(16, jobs, job_ind)
+    planes = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
+    for lo in range(0, len(pairs), batch):
+        sub = pairs[lo:lo + batch]
+        ob = np.stack([folded[a] ^ folded[b] for a, b in sub])
+        hb = np.stack([folded[a] & folded[b] for a, b in sub])
+        post, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
+        O.augment_sum_over_pairs(pm, post, len(sub), ob, hb, *planes)
+    return planes
+
+
+def _sums_worker(rank, world, port, out_path, order):
+    from fastsmc_amd.dist import SUM_PLANES, reduce_sums
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pm, folded = _sums_problem()
+    mine = _job_sums(pm, folded, world, rank + 1)
+    total = reduce_sums(dict(zip(SUM_PLANES, mine)), dist, rank, world, order=order)
+    if order == "rank":
+        assert (total is None) == (rank != 0)
+    if total is not None:
+        np.savez(f"{out_path}.{rank}.npz", **total)
+    np.savez(f"{out_path}.part{rank}.npz", *mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sum_over_pairs_reduced_in_rank_order(tmp_path, world):
+    """Every rank decodes job rank+1 of `world` (the reference's decomposition) and `reduce_sums` merges the planes on
+    rank 0 job after job, PosteriorMerger's order: EXACTLY ((0 + P_0) + P_1) + ..., and within 1e-6 relative of the sums
+    of one process that decodes all the pairs (the only difference is fp32 re-association at the shard joins)."""
+    from fastsmc_amd.dist import SUM_PLANES
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sums")
+    mp.spawn(_sums_worker, args=(world, port, out, "rank"), nprocs=world, join=True)
+    got = np.load(f"{out}.0.npz")
+    assert not os.path.exists(f"{out}.1.npz")
+    parts = [[np.load(f"{out}.part{r}.npz")[f"arr_{i}"] for i in range(4)] for r in range(world)]
+    pm, folded = _sums_problem()
+    single = _job_sums(pm, folded, 1, 1)
+    for i, name in enumerate(SUM_PLANES):
+        acc = np.zeros_like(parts[0][i])
+        for r in range(world):
+            acc = acc + parts[r][i]
+        np.testing.assert_array_equal(got[name], acc)             # the merge order, bit for bit
+        np.testing.assert_allclose(got[name], single[i], rtol=1e-6, atol=1e-7)  # one process: re-association only
+        assert single[i].any()
+    np.testing.assert_allclose(got["sumOverPairs"], got["sumOverPairs00"] + got["sumOverPairs01"] + got["sumOverPairs11"],
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_sum_over_pairs_all_reduce_variant(tmp_path):
+    """`order="allreduce"`: every rank gets the total; flagged as re-associating -- compared within tolerance only."""
+    from fastsmc_amd.dist import SUM_PLANES, reduce_sums
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sums")
+    mp.spawn(_sums_worker, args=(2, port, out, "allreduce"), nprocs=2, join=True)
+    a, b = np.load(f"{out}.0.npz"), np.load(f"{out}.1.npz")
+    pm, folded = _sums_problem()
+    single = _job_sums(pm, folded, 1, 1)
+    for i, name in enumerate(SUM_PLANES):
+        np.testing.assert_array_equal(a[name], b[name])
+        np.testing.assert_allclose(a[name], single[i], rtol=1e-6, atol=1e-7)
+    # one process, no group: the planes as they are; planes a decode did not ask for are left out
+    alone = reduce_sums({"sumOverPairs": single[0], "sumOverPairs00": np.zeros((0, 0), np.float32)})
+    assert list(alone) == ["sumOverPairs"] and np.array_equal(alone["sumOverPairs"], single[0])
+    with pytest.raises(ValueError):
+        reduce_sums(single, order="tree")

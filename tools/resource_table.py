@@ -2,7 +2,7 @@
 """Per-kernel resource table of the HIP library as the compiler reports it (-Rpass-analysis=kernel-resource-usage): VGPRs,
 AGPRs, spilled VGPRs / SGPRs, scratch bytes per lane, LDS bytes per workgroup, waves per SIMD -- one row per
 instantiation of every family member, stamped with the hash of the sources they were compiled from.
-Usage: tools/resource_table.py [out.json]   (default profiles/r03_kernel_resources.json; no GPU needed)"""
+Usage: tools/resource_table.py [out.json]   (default profiles/r05_kernel_resources.json; no GPU needed)"""
 import json
 import os
 import re
@@ -12,7 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from fastsmc_amd.build import HIPCC_FLAGS, KT_MEMBERS, W2_MEMBERS, hip_source_hash  # noqa: E402
+from fastsmc_amd.build import (EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, W2_MEMBERS, exact_define,  # noqa: E402
+                               hip_source_hash)
 
 FIELDS = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
           "Occupancy [waves/SIMD]": "waves_per_simd", "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills",
@@ -25,7 +26,7 @@ def demangle(names):
 
 
 def member(define):
-    flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + exact_define()
     r = subprocess.run(["hipcc", *flags, *define.split(), "-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
                         "-Wno-unused-command-line-argument", "-o", "/dev/null",
                         os.path.join(ROOT, "fastsmc_amd", "csrc", "fsmc_inst.hip")], capture_output=True, text=True)
@@ -44,8 +45,10 @@ def member(define):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_kernel_resources.json")
-    defs = [f"-DFSMC_INSTANCE_KT={k}" for k in KT_MEMBERS] + [f"-DFSMC_INSTANCE_W2={kh} -DFSMC_INSTANCE_NW={nw}" for kh, nw in W2_MEMBERS]
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_kernel_resources.json")
+    # every member the build compiles (fastsmc_amd/build.py): padded and exact lane-per-pair members, wave-group members
+    defs = ([f"-DFSMC_INSTANCE_KT={k}" for k in KT_MEMBERS + EXACT_MEMBERS]
+            + [f"-DFSMC_INSTANCE_W2={kh} -DFSMC_INSTANCE_NW={nw}" for kh, nw in W2_MEMBERS])
     with ThreadPoolExecutor(max_workers=min(len(defs), os.cpu_count() or 1)) as ex:
         rows = [r for rs in ex.map(member, defs) for r in rs]
     for r, name in zip(rows, demangle([r["mangled"] for r in rows])):
@@ -54,7 +57,7 @@ def main():
     rows.sort(key=lambda r: r["kernel"])
     doc = {"lib_hash": hip_source_hash(), "flags": " ".join(HIPCC_FLAGS),
            "template_arguments": {"decode_kernel": "<KT, MODE (0 IBD, 1 dump, 2 per pair, 3 sums), TRACK, SEQ, HALF, DUAL>",
-                                  "decode_kernel_w2": "<KH, MODE, TRACK, SEQ>"},
+                                  "decode_kernel_w2": "<KH, MODE, TRACK, SEQ, NW>"},
            "kernels": rows}
     json.dump(doc, open(out, "w"), indent=1)
     print(f"{len(rows)} kernels -> {out}")
