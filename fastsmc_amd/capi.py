@@ -28,7 +28,7 @@ SYMBOLS = [
     "fsmc_ctx_create", "fsmc_ctx_destroy", "fsmc_last_error", "fsmc_ctx_info", "fsmc_ctx_set_workspace_limit",
     "fsmc_ctx_expect_work",
     "fsmc_ctx_set_chunk_sites", "fsmc_ctx_set_beta_stride", "fsmc_ctx_last_beta_stride", "fsmc_ctx_last_plan",
-    "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items", "fsmc_ctx_last_segment_sums_in_lds", "fsmc_ctx_set_resident_chunks",
+    "fsmc_ctx_last_kernel", "fsmc_ctx_set_pairing", "fsmc_ctx_last_items", "fsmc_ctx_set_two_wave_windows", "fsmc_ctx_last_waves_per_window", "fsmc_ctx_last_segment_sums_in_lds", "fsmc_ctx_set_resident_chunks",
     "fsmc_ctx_last_resident_chunks",
     "fsmc_model_create", "fsmc_model_destroy", "fsmc_haps_upload", "fsmc_worklist_upload",
     "fsmc_decode_ibd_launch", "fsmc_decode_ibd_fetch", "fsmc_sync", "fsmc_last_kernel_ms", "fsmc_phase_cycles",
@@ -102,6 +102,8 @@ def load():
         L.fsmc_ctx_last_plan.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.fsmc_ctx_last_kernel.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_ctx_set_pairing.argtypes = [vp, u32]
+        L.fsmc_ctx_set_two_wave_windows.argtypes = [vp, u32]
+        L.fsmc_ctx_last_waves_per_window.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_ctx_last_items.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_ctx_last_segment_sums_in_lds.argtypes = [vp, C.POINTER(i32)]
         L.fsmc_model_create.argtypes = [vp, C.POINTER(_ModelDesc), C.POINTER(vp)]
@@ -210,6 +212,15 @@ class Context:
         four-waves-per-group kernel with KH states per wave."""
         v = C.c_int32(0)
         self._check(self._L.fsmc_ctx_last_kernel(self._h, C.byref(v)))
+        return v.value
+
+    def set_two_wave_windows(self, mode: int):
+        """0 = automatic (small launches of the dump / per-pair / sums consumers give a window two waves), 1 = never."""
+        self._check(self._L.fsmc_ctx_set_two_wave_windows(self._h, mode))
+
+    def last_waves_per_window(self) -> int:
+        v = C.c_int32(0)
+        self._check(self._L.fsmc_ctx_last_waves_per_window(self._h, C.byref(v)))
         return v.value
 
     def set_pairing(self, mode: int):

@@ -8,6 +8,7 @@ namespace fsmc
 {
 #if defined(FSMC_INSTANCE_KT)
 FSMC_KT_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
+FSMC_KT_BIDIR_KERNELS(FSMC_DEFINE_KT_BIDIR, FSMC_INSTANCE_KT)
 #if FSMC_INSTANCE_KT > 0
 FSMC_DEFINE_KT_DUAL(FSMC_INSTANCE_KT)
 #endif

@@ -12,6 +12,9 @@
 //   exact members (FSMC_EXACT_KT, default 50 and 100; any K that is not a multiple of 16 may be listed at build time:
 //   `FSMC_EXACT_MEMBERS="50 100 75" python -m fastsmc_amd.build`): a model of exactly that many states runs without
 //   ghost states, masks and run-time state counts -- what the 69-state member is to the reference's own files
+// Two waves per window (decode_kernel_bidir<KT, MODE>, fsmc_kernels_bidir.h): the same members' dump / per-pair / sums
+//   consumers in array mode for launches that leave half the chip empty -- alpha from the window's start in one wave while
+//   beta comes from its end in another.
 // Wave-group kernel (decode_kernel_w2<KH, MODE, TRACK, SEQ, NW>), lane = pair and NW waves per group of KH states each:
 //   128 < K <= 256: four waves of 48 or 64 states; 256 < K <= 320: four waves of 80; 320 < K <= 512: six, seven or
 //   eight waves of 64.
@@ -23,6 +26,7 @@
 
 #include "fsmc_kernels.h"
 #include "fsmc_kernels_any.h"
+#include "fsmc_kernels_bidir.h"
 #include "fsmc_kernels_w2.h"
 
 namespace fsmc
@@ -63,6 +67,10 @@ constexpr bool halfBuilt(const int KT)
   extern template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
 #define FSMC_DEFINE_KT(KT, MODE, TRACK, SEQ, HALF)                                                                     \
   template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
+// two waves per window (fsmc_kernels_bidir.h): the consumers without state across sites, array mode, small launches
+#define FSMC_KT_BIDIR_KERNELS(X, KT) X(KT, kModeDump) X(KT, kModePerPair) X(KT, kModeSums)
+#define FSMC_DECLARE_KT_BIDIR(KT, MODE) extern template __global__ void decode_kernel_bidir<KT, MODE>(const KParams);
+#define FSMC_DEFINE_KT_BIDIR(KT, MODE) template __global__ void decode_kernel_bidir<KT, MODE>(const KParams);
 // two half-groups per wavefront (hashing-mode work lists): array-mode IBD decode, beta stride 1
 #define FSMC_DECLARE_KT_DUAL(KT)                                                                                       \
   extern template __global__ void decode_kernel<KT, kModeIbd, true, false, false, true>(const KParams);              \
@@ -99,11 +107,12 @@ constexpr bool halfBuilt(const int KT)
 #define FSMC_ALL_W2(Y) Y(48, 4) Y(64, 4) Y(80, 4) Y(64, 6) Y(64, 7) Y(64, 8)
 
 #if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_W2)
-#define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)
+#define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT) FSMC_KT_BIDIR_KERNELS(FSMC_DECLARE_KT_BIDIR, KT)
 FSMC_ALL_KT(FSMC_DECLARE_MEMBER)
 #define FSMC_DECLARE_EXACT_MEMBER(KT)                                                                                   \
   static_assert(KT % 16 != 0 && KT <= 128, "an exact member is not a multiple of 16 states and has at most 128");       \
   FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)                                                                                  \
+  FSMC_KT_BIDIR_KERNELS(FSMC_DECLARE_KT_BIDIR, KT)                                                                      \
   FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, KT)                                                                             \
   FSMC_DECLARE_KT_DUAL_HALF(KT)                                                                                         \
   FSMC_DECLARE_KT_DUAL(KT)

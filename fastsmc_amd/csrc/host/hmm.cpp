@@ -555,8 +555,24 @@ fsmc_ctx* HMM::engine()
   return mCtx;
 }
 
+namespace
+{
+// FSMC_HOST_TIMING: wall-clock marks of a job's phases on stderr (seconds since the first mark of the process)
+void hostMark(const char* what)
+{
+  static const bool on = std::getenv("FSMC_HOST_TIMING") != nullptr;
+  if (!on) {
+    return;
+  }
+  using Clock = std::chrono::steady_clock;
+  static const Clock::time_point t0 = Clock::now();
+  std::fprintf(stderr, "[fsmc host] %8.3f s  %s\n", std::chrono::duration<double>(Clock::now() - t0).count(), what);
+}
+} // namespace
+
 void HMM::ensureEngine()
 {
+  hostMark("engine: open");
   engine();
   if (!mModel) {
     fsmc_model_desc d{};
@@ -586,6 +602,7 @@ void HMM::ensureEngine()
       d.hom = mPrep.hom.data();
     }
     check(mCtx, fsmc_model_create(mCtx, &d, &mModel), "fsmc_model_create");
+    hostMark("engine: model on the device");
   }
   if (!mHapsUploaded) {
     check(mCtx,
@@ -593,6 +610,7 @@ void HMM::ensureEngine()
                            static_cast<uint32_t>(mData.sites)),
           "fsmc_haps_upload");
     mHapsUploaded = true;
+    hostMark("engine: haplotypes on the device");
   }
 }
 
@@ -719,6 +737,7 @@ void HMM::flush()
   check(mCtx, fsmc_worklist_upload(mCtx, mPairs.data(), nPairs, mGroups.data(), mGroups.size()),
         "fsmc_worklist_upload");
   mTimeUpload += since(t0);
+  hostMark("flush: work list uploaded");
 
   if (mParams.FastSMC) {
     uint32_t flags = 0;
@@ -726,6 +745,7 @@ void HMM::flush()
     if (mParams.doPerPairMAP) flags |= FSMC_WANT_MAP;
     t0 = Clock::now();
     check(mCtx, fsmc_decode_ibd_launch(mCtx, mModel, flags), "fsmc_decode_ibd_launch");
+    hostMark("flush: kernel launched");
     std::vector<fsmc_ibd_record> recs(std::max<size_t>(1024, 4 * nPairs));
     size_t n = 0;
     int rc = fsmc_decode_ibd_fetch(mCtx, recs.data(), recs.size(), &n);
@@ -735,6 +755,7 @@ void HMM::flush()
     }
     check(mCtx, rc, "fsmc_decode_ibd_fetch");
     mTimeDecode += since(t0);
+    hostMark("flush: records fetched");
     t0 = Clock::now();
     for (size_t i = 0; i < n; ++i) {
       if (mKeepRecords) {
@@ -992,6 +1013,7 @@ std::vector<std::pair<unsigned, unsigned>> HMM::pairsOfJob(int jobs, int jobInd)
 
 void HMM::decodeAll(int jobs, int jobInd)
 {
+  hostMark("decodeAll: start");
   resetDecoding();
   if (mParams.FastSMC) {
     openIbdFile(jobs, jobInd);
@@ -1007,7 +1029,9 @@ void HMM::decodeAll(int jobs, int jobInd)
     announceWork(static_cast<double>(nPairsOfJob) * static_cast<double>(mData.sites));
   }
   forEachPairOfJob(jobs, jobInd, true, [&](unsigned a, unsigned b) { queuePair(a, b); });
+  hostMark("decodeAll: pairs queued");
   finishDecoding();
+  hostMark("decodeAll: done");
 }
 
 void HMM::announceWork(double pairSites)

@@ -165,6 +165,15 @@ int fsmc_ctx_last_resident_chunks(const fsmc_ctx* ctx, int32_t* chunks);
  * fsmc_ctx_last_items: wave work items of the last IBD launch when it paired groups, 0 when it ran them as uploaded. */
 int fsmc_ctx_set_pairing(fsmc_ctx* ctx, uint32_t mode);
 int fsmc_ctx_last_items(const fsmc_ctx* ctx, int32_t* n_items);
+/* Two waves per decode window.  The consumers without state across sites (fsmc_decode_posteriors, fsmc_decode_per_pair,
+ * fsmc_decode_sums*) of a model of at most 128 states in array mode: a launch of at most half as many groups (batches of
+ * the sums) as the chip holds waves gives every group a workgroup of two waves -- alpha runs up from the window's first
+ * site in one while beta runs down from its last in the other, each stores its rows as far as the middle and combines
+ * with the other's beyond it (HMM.cpp:672-691, 725-1041: one alpha step, one beta step and one combine per site, the
+ * same operations in the same order: results do not depend on it) -- provided the whole windows' rows fit the
+ * workspace.  0 (default) = automatic, 1 = never.  fsmc_ctx_last_waves_per_window: 2 if the last such launch did. */
+int fsmc_ctx_set_two_wave_windows(fsmc_ctx* ctx, uint32_t mode);
+int fsmc_ctx_last_waves_per_window(const fsmc_ctx* ctx, int32_t* waves);
 /* 1 when the last IBD launch kept the open segments' per-state posterior sums (FSMC_WANT_MEAN / FSMC_WANT_MAP:
  * HMM.cpp:1212-1229) in LDS instead of the workspace: a launch of fewer wavefronts than the chip's LDS can give
  * (K/4 + 1) KiB each beside the kernel's own -- a small job, whose waves would wait out every round trip of those sums
@@ -247,7 +256,9 @@ int fsmc_identify_ex(fsmc_ctx* ctx, const uint64_t* words, uint32_t n_haps, uint
 int fsmc_identify_fetch(fsmc_ctx* ctx, fsmc_candidate* out, size_t cap, size_t* n_out);
 
 int fsmc_sync(fsmc_ctx* ctx);
-/* Device time (ms, hipEvent) of the last decode launch's kernel(s); valid after a sync/fetch. */
+/* Device time (ms, hipEvent) of the last decode call's kernel(s) -- a call of several launches (the sums of more batches
+ * than fit one launch) from its first launch to the end of its last, the plane additions in between included; valid
+ * after a sync/fetch. */
 int fsmc_last_kernel_ms(fsmc_ctx* ctx, float* ms);
 
 /* Diagnostic: shader-clock cycles summed over waves since the last call, {pass B, beta rebuild, alpha sweep,

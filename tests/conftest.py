@@ -39,6 +39,15 @@ def expected_member(K):
     return 1000 + kh if nw == 4 else 1000 * nw + kh
 
 
+@pytest.fixture(params=["two-waves-auto", "one-wave"])
+def window_waves(request, monkeypatch):
+    """The dump / per-pair / sums consumers of a small launch run two waves per window (csrc/fsmc_kernels_bidir.h); the
+    tests of a module that asks for this fixture run once that way and once on the one-wave kernels."""
+    if request.param == "one-wave":
+        monkeypatch.setenv("FSMC_DIAG_TWO_WAVE_WINDOWS", "never")
+    return request.param
+
+
 def build_small_problem():
     """A seeded synthetic problem small enough for the CPU oracle: 64 haplotypes x 640 sites, K = 69."""
     import numpy as np

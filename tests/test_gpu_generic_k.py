@@ -50,30 +50,34 @@ def test_generic_kernel_matches_oracle(K):
     for f_got, f_want in (("pair", "pair"), ("start", "start"), ("end", "end"), ("prob", "prob"),
                           ("post_mean", "postMean"), ("map", "map")):
         np.testing.assert_array_equal(got[f_got], want[f_want], err_msg=f_got)
-    # posterior, per-pair mean/MAP and sums for the first group
-    ctx.upload_worklist(pr[:64], capi.whole_sequence_groups(64, pm.S))
-    post = ctx.decode_posteriors(model)[0]
-    assert ctx.last_kernel() == _member(K)
-    ob = np.stack([folded[a] ^ folded[b] for a, b in pairs[:64]])
-    hb = np.stack([folded[a] & folded[b] for a, b in pairs[:64]])
-    wpost, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
-    np.testing.assert_array_equal(post, wpost)
-    mean, mp = ctx.decode_per_pair(model, pm.exp_times)
-    assert ctx.last_kernel() == _member(K, "per_pair")
-    wmean, wmap, _ = O.per_pair_output(pm, wpost, 64)
-    np.testing.assert_array_equal(mean, wmean)
-    np.testing.assert_array_equal(mp, wmap)
-    s, _ = ctx.decode_sums(model)  # (K = 256 included: the transposition tile is sized for it)
-    assert ctx.last_kernel() == _member(K)
-    wsum = np.zeros((pm.S, pm.K), np.float32)
-    O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
-    np.testing.assert_array_equal(s, wsum)
-    if K in (5, 100, 200, 256, 300, 402, 520):  # the 00 / 01 / 11 split in one member of each kernel
-        s2, mm = ctx.decode_sums(model, major_minor=True)
-        want = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
-        O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, want[0], want[1], want[2], want[3])
-        for got, w in zip((s2, *mm), want):
-            np.testing.assert_array_equal(got, w)
+    # (K <= 128, array mode: once with two waves per window -- this launch qualifies -- and once on the one-wave kernel)
+    for two_wave in ((0, 1) if K <= 128 else (0,)):
+        ctx.set_two_wave_windows(two_wave)
+        # posterior, per-pair mean/MAP and sums for the first group
+        ctx.upload_worklist(pr[:64], capi.whole_sequence_groups(64, pm.S))
+        post = ctx.decode_posteriors(model)[0]
+        assert ctx.last_kernel() == _member(K)
+        ob = np.stack([folded[a] ^ folded[b] for a, b in pairs[:64]])
+        hb = np.stack([folded[a] & folded[b] for a, b in pairs[:64]])
+        wpost, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
+        np.testing.assert_array_equal(post, wpost)
+        mean, mp = ctx.decode_per_pair(model, pm.exp_times)
+        assert ctx.last_kernel() == _member(K, "per_pair")
+        wmean, wmap, _ = O.per_pair_output(pm, wpost, 64)
+        np.testing.assert_array_equal(mean, wmean)
+        np.testing.assert_array_equal(mp, wmap)
+        s, _ = ctx.decode_sums(model)  # (K = 256 included: the transposition tile is sized for it)
+        assert ctx.last_waves_per_window() == (2 if K <= 112 and two_wave == 0 else 1)
+        assert ctx.last_kernel() == _member(K)
+        wsum = np.zeros((pm.S, pm.K), np.float32)
+        O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
+        np.testing.assert_array_equal(s, wsum)
+        if K in (5, 100, 200, 256, 300, 402, 520):  # the 00 / 01 / 11 split in one member of each kernel
+            s2, mm = ctx.decode_sums(model, major_minor=True)
+            want = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
+            O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, want[0], want[1], want[2], want[3])
+            for got, w in zip((s2, *mm), want):
+                np.testing.assert_array_equal(got, w)
     ctx.close()
 
 

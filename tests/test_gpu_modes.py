@@ -9,7 +9,7 @@ import pytest
 from fastsmc_amd import api, capi, synth
 from oracle import oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("window_waves")]
 
 
 @pytest.fixture(scope="module")

@@ -60,10 +60,20 @@ def test_decode_all_writes_the_per_pair_files(small_problem, tmp_path, batch):
         want_map += O.eigen_format_rows(wmap)
     assert got_mean == want_mean
     assert got_map == want_map
-    # the values themselves, whatever the text: parsed back, the means are the oracle's to the 6 printed digits and the
-    # MAP states exactly (the joined rows at the batch boundaries hold two pairs' values)
+    # the values themselves, whatever the text: parsed back batch by batch (nothing separates a batch's last value from
+    # the next batch's first), the means are the oracle's to the 6 printed digits
+    def parse(text, digits):
+        vals, at = [], 0
+        for chunk, post in _batches(sp, pm, pairs, batch):
+            wmean = O.per_pair_output(pm, post, len(chunk))[0]
+            n = sum(len("%.*g" % (digits, float(x))) for x in wmean.reshape(-1)) + wmean.size - 1  # values + separators
+            vals.append(np.array(text[at:at + n].split(), np.float64))
+            at += n
+        assert at == len(text)
+        return np.concatenate(vals)
+
     all_mean = np.concatenate([O.per_pair_output(pm, post, len(chunk))[0].reshape(-1) for chunk, post in _batches(sp, pm, pairs, batch)])
-    np.testing.assert_allclose(np.array(got_mean.split(), np.float64), all_mean, rtol=5e-6)
+    np.testing.assert_allclose(parse(got_mean, 6), all_mean, rtol=5e-6)
     # Eigen 5 / master print max_digits10 = 9 digits where Eigen 3.4 prints 6: the environment switch writes that file,
     # whose values round-trip to the float32 means bit for bit
     import os
@@ -74,7 +84,7 @@ def test_decode_all_writes_the_per_pair_files(small_problem, tmp_path, batch):
         del os.environ["FSMC_EIGEN_FULL_PRECISION_DIGITS"]
     nine = gzip.open(root + ".perPairPosteriorMeans.gz", "rt").read()
     assert nine != got_mean
-    np.testing.assert_array_equal(np.array(nine.split(), np.float64).astype(np.float32), all_mean.astype(np.float32))
+    np.testing.assert_array_equal(parse(nine, 9).astype(np.float32), all_mean.astype(np.float32))
     # one row per pair, minus the joins at the batch boundaries
     n_batches = (len(pairs) + batch - 1) // batch
     assert got_map.count("\n") == len(pairs) - n_batches

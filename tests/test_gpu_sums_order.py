@@ -9,7 +9,7 @@ import pytest
 from fastsmc_amd import capi, synth
 from oracle import oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("window_waves")]
 
 
 def _problem(K=69, n_hap=96, S=1500, seed=3):

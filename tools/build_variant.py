@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--capi", action="store_true")
     ap.add_argument("--src-dir", default=CSRC)
     ap.add_argument("--resources", default="")
+    ap.add_argument("--units", default="", help="comma-separated unit names (kt112, w2_64x6 ...): only these are recompiled")
     args = ap.parse_args(argv)
     out_dir = os.path.join(ROOT, "fastsmc_amd", "variants")
     obj = os.path.join(out_dir, "obj_" + args.name)
@@ -52,6 +53,9 @@ def main():
     units = {"all": kt + w2 + rest + capi, "w2": w2, "kt": kt}[args.only]
     if args.capi and args.only != "all":
         units = units + capi
+    if args.units:
+        want = set(args.units.split(","))
+        units = [u for u in kt + w2 + rest + capi if u[0] in want]
     names = {u[0] for u in units}
 
     def compile_unit(u):

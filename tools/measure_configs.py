@@ -94,6 +94,48 @@ def c1():
     ctx.close()
 
 
+def c1_consumers():
+    """The consumers without state across sites on the C1 shape -- sums over all 44 850 pairs (701 groups), per-pair mean /
+    MAP rows of all pairs, posterior dump of the first 8192 (128 groups) and 1024 pairs (16 groups: an ASMC.decodePairs
+    list) -- with two waves per window (the library's choice for a launch this small, csrc/fsmc_kernels_bidir.h) and on
+    the one-wave kernel, interleaved on one box."""
+    pm, bits, _, _ = prepared(300, 6760, 69)
+    pairs = all_pairs(150)
+    ctx = capi.Context(0)
+    long_job_workspace(ctx)
+    model = ctx.create_model(pm)
+    ctx.upload_haps(bits, pm.S)
+
+    def kernel_ms(fn, reps):
+        fn()
+        ms = []
+        for _ in range(reps):
+            fn()
+            ms.append(ctx.last_kernel_ms())
+        return float(np.mean(ms))
+
+    def use(n):
+        ctx.upload_worklist(pairs[:n].view(capi.PAIR_DTYPE).reshape(-1), capi.whole_sequence_groups(n, pm.S, batch=64))
+
+    for name, n, fn in (("sums", pairs.shape[0], lambda: ctx.decode_sums(model)),
+                        ("sums_00_01_11", pairs.shape[0], lambda: ctx.decode_sums(model, major_minor=True)),
+                        ("per_pair", pairs.shape[0], lambda: ctx.decode_per_pair(model, pm.exp_times)),
+                        ("dump_8192", 8192, lambda: ctx.decode_posteriors(model)),
+                        ("dump_1024", 1024, lambda: ctx.decode_posteriors(model))):
+        use(n)
+        line = {"config": "c1_" + name, "pairs": int(n), "groups": (int(n) + 63) // 64}
+        for rep in range(2):
+            for mode, key in ((0, "two_waves_ms"), (1, "one_wave_ms")):
+                ctx.set_two_wave_windows(mode)
+                line.setdefault(key, []).append(kernel_ms(fn, 3))
+                line["waves_per_window_" + key[:3]] = ctx.last_waves_per_window()
+        algo = float(n) * pm.S * (8 * pm.K + 0.25)
+        line["frac_two_waves"] = algo / (min(line["two_waves_ms"]) / 1e3) / 8e12
+        line["frac_one_wave"] = algo / (min(line["one_wave_ms"]) / 1e3) / 8e12
+        print(json.dumps(line))
+    ctx.close()
+
+
 def k256(K=256):
     pm, bits, _, _ = prepared(600, 3000, K)  # 179 700 pairs = 2808 groups: every resident wave has work
     pairs = all_pairs(300)
@@ -480,7 +522,7 @@ def identify():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
-        {"c1": c1, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "k300": lambda: k256(300), "k320": lambda: k256(320), "k350": lambda: k256(350), "k402": lambda: k256(402),
+        {"c1": c1, "c1_consumers": c1_consumers, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "k300": lambda: k256(300), "k320": lambda: k256(320), "k350": lambda: k256(350), "k402": lambda: k256(402),
          "k448": lambda: k256(448), "k500": lambda: k256(500), "k600": lambda: k256(600), "hashing": hashing,
          "short": short_windows, "run_c2": run_c2, "ingest_c3": ingest_c3, "c5_job": c5_job,
          "ingest_small": lambda: ingest_c3(2000, 20000), "identify": identify, "seq": seq, "seq100": lambda: seq(100)}[w]()
