@@ -42,7 +42,7 @@ HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); ~6.3e12 is the meas
 METRIC = "haplotype-pairs decoded/sec (whole node) + GB/s vs HBM roofline, 69-state HMM"
 C3_PAIRS = 1 << 20
 C3_SEED = 20260
-PROFILE_ROUND = "r04"  # profiles/<round>_traffic.json, <round>_c3_n1.json: the committed measurements of this build
+PROFILE_ROUND = "r05"  # profiles/<round>_traffic.json, <round>_c3_n1.json: the committed measurements of this build
 
 
 def lib_hash() -> str:

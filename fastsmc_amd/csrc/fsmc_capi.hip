@@ -331,7 +331,8 @@ W2Member w2Member(int K)
   // (diagnostic: FSMC_DIAG_W2_MEMBER="<waves>x<states per wave>" picks another member that holds the model -- A/B runs)
   if (const char* v = std::getenv("FSMC_DIAG_W2_MEMBER")) {
     int nw = 0, kh = 0;
-    if (std::sscanf(v, "%dx%d", &nw, &kh) == 2 && nw * kh >= K) {
+    // (a member whose waves the model fills all but the last of, or the 48-state one: where the kernel masks ghosts)
+    if (std::sscanf(v, "%dx%d", &nw, &kh) == 2 && nw * kh >= K && ((nw - 1) * kh < K || (kh == 48 && 2 * kh < K))) {
 #define FSMC_IS_W2(KHX, NWX)                                                                                            \
   if (kh == KHX && nw == NWX) {                                                                                        \
     return {nw, kh};                                                                                                   \

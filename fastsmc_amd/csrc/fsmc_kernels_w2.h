@@ -307,6 +307,13 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
   };
   // ---- ascending pass: BL[k] = BL[k-1] + B[k-1]*vec[k-1];  x[k] = BL[k] + D[k]*vec[k]
   // wave 0 runs it in phase 0 (BL[0] = 0; it also forms vec), wave 1 in phase 1 from wave 0's BL of state KH
+  // Ghost states (K ... KP-1) lie in the LAST wave only -- a model is given the member whose waves it fills all but the
+  // last of -- except at 48 states a wave (K = 129 ... 192: from 129 to 143 states the third wave has ghosts too): only
+  // those waves multiply their row by the 1/0 mask (and load it).
+  // (An instantiation WITHOUT any mask for models that fill every wave -- config 4's 256 = 4 x 64 states -- was built and
+  //  measured in round 5: 3 % SLOWER at size and 8 % on 3000-site windows, interleaved on one box: the allocator's luck,
+  //  not the instruction count, decides this kernel.  Not kept.)
+  constexpr bool kMasked = KH == 48 ? (2 * H >= NW) : (H == NW - 1);
   auto ascending = [&](auto blockStates, const float blIn, const bool first) {
     constexpr int BS = decltype(blockStates)::value;
     constexpr int NB = KH / BS;
@@ -321,7 +328,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
     touchRow<1, kLines - 1>(tbt, rsw, kRowB * KP);
     if (first) {
       em = readEmis<BS>(e, 0);
-    } else {
+    } else if constexpr (kMasked) {
       mk = LD<BS, false>::loadAt(gmw, 0);
     }
     float BL = blIn;
@@ -334,7 +341,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         bt = nbt;
         if (first) {
           em = nem;
-        } else {
+        } else if constexpr (kMasked) {
           landed(nmk);
           mk = nmk;
         }
@@ -342,8 +349,10 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         landed(d, bt);
         heldRow<kLines - 1>(td);
         heldRow<kLines - 1>(tbt);
-        if (!first) {
-          landed(mk);
+        if constexpr (kMasked) {
+          if (!first) {
+            landed(mk);
+          }
         }
       }
       if (blk + 1 < NB) {
@@ -351,7 +360,7 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         nbt = LD<BS, false>::loadAt(rsw, kRowB * KP + (blk + 1) * BS);
         if (first) {
           nem = readEmis<BS>(e, blk + 1);
-        } else {
+        } else if constexpr (kMasked) {
           nmk = LD<BS, false>::loadAt(gmw, (blk + 1) * BS);
         }
       }
@@ -381,7 +390,9 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
         if (!first) {
           const f32x2 bu = {w[k], w[k + 1]};
           x = padd(x, bu);
-          x = pmul(x, pairOf(mk, i));
+          if constexpr (kMasked) {
+            x = pmul(x, pairOf(mk, i));
+          }
         }
         w[k] = x.x;
         w[k + 1] = x.y;

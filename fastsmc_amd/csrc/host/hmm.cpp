@@ -967,7 +967,7 @@ void HMM::writeIbdRecordsTo(const std::string& fileName, const std::vector<fsmc_
   gzclose(file);
 }
 
-template <typename Fn> void HMM::forEachPairOfJob(int jobs, int jobInd, bool shardOnly, Fn&& fn) const
+std::pair<unsigned long long, unsigned long long> HMM::pairRangeOfJob(int jobs, int jobInd, bool shardOnly) const
 {
   const unsigned long long N = mData.numIndividuals();
   // pair range of this job (HMM.cpp:310-321)
@@ -982,15 +982,33 @@ template <typename Fn> void HMM::forEachPairOfJob(int jobs, int jobInd, bool sha
     lo = std::min(pairsEnd, pairsStart + batchLo * B);
     hi = std::min(pairsEnd, pairsStart + batchHi * B);
   }
+  return {lo, hi};
+}
+
+template <typename Fn> void HMM::forEachPairOfJob(int jobs, int jobInd, bool shardOnly, Fn&& fn) const
+{
+  const unsigned long long N = mData.numIndividuals();
+  const auto [lo, hi] = pairRangeOfJob(jobs, jobInd, shardOnly);
+  // individual i contributes the 4 * i cross pairs with every j < i and then its own two haplotypes: its block starts
+  // at ordinal 2 * i * i - i (HMM.cpp:325-357); blocks outside [lo, hi) are skipped whole
   unsigned long long pairs = 0;
-  for (unsigned i = 0; i < N; i++) {
+  for (unsigned long long i = 0; i < N && pairs < hi; i++) {
+    const unsigned long long block = mParams.withinOnly ? 1ull : 4ull * i + 1ull;
+    if (pairs + block <= lo) {
+      pairs += block;
+      continue;
+    }
     if (!mParams.withinOnly) {
-      for (unsigned j = 0; j < i; j++) {
+      for (unsigned long long j = 0; j < i; j++) {
+        if (pairs + 4 <= lo || pairs >= hi) {
+          pairs += 4;
+          continue;
+        }
         for (int iHap = 1; iHap <= 2; iHap++) {
           for (int jHap = 1; jHap <= 2; jHap++) {
             if (lo <= pairs && pairs < hi) {
               // makePairObs(jHap, j, iHap, i): the lower-numbered individual is the record's first id
-              fn(static_cast<unsigned>(dipToHapId(j, jHap)), static_cast<unsigned>(dipToHapId(i, iHap)));
+              fn(static_cast<unsigned>(2 * j + jHap - 1), static_cast<unsigned>(2 * i + iHap - 1));
             }
             pairs++;
           }
@@ -998,7 +1016,7 @@ template <typename Fn> void HMM::forEachPairOfJob(int jobs, int jobInd, bool sha
       }
     }
     if (lo <= pairs && pairs < hi) {
-      fn(static_cast<unsigned>(dipToHapId(i, 1)), static_cast<unsigned>(dipToHapId(i, 2)));
+      fn(static_cast<unsigned>(2 * i), static_cast<unsigned>(2 * i + 1));
     }
     pairs++;
   }
@@ -1023,10 +1041,14 @@ void HMM::decodeAll(int jobs, int jobInd)
   }
   // the job's size is known here (its pair range, HMM.cpp:310-321): announce it, so that a long job under the
   // library's own workspace policy allocates once at its start instead of growing into the card (fsmc_ctx_expect_work)
-  unsigned long long nPairsOfJob = 0;
-  forEachPairOfJob(jobs, jobInd, true, [&](unsigned, unsigned) { nPairsOfJob++; });
+  const auto [pairLo, pairHi] = pairRangeOfJob(jobs, jobInd, true);
+  const unsigned long long nPairsOfJob = pairHi - pairLo;
   if (nPairsOfJob) {
     announceWork(static_cast<double>(nPairsOfJob) * static_cast<double>(mData.sites));
+    // (the work list of a flush: at most the flush threshold plus a batch)
+    const size_t expect = static_cast<size_t>(std::min<unsigned long long>(nPairsOfJob, mFlushThreshold + 64));
+    mPairs.reserve(mPairs.size() + expect);
+    mGroups.reserve(mGroups.size() + expect / 32 + 2);
   }
   forEachPairOfJob(jobs, jobInd, true, [&](unsigned a, unsigned b) { queuePair(a, b); });
   hostMark("decodeAll: pairs queued");

@@ -180,6 +180,8 @@ private:
   void prepareModel();
   void ensureEngine();
   template <typename Fn> void forEachPairOfJob(int jobs, int jobInd, bool shardOnly, Fn&& fn) const;
+  // [lo, hi) ordinals of the job's (or, shardOnly, this device's) pairs in the enumeration of HMM.cpp:325-357
+  std::pair<unsigned long long, unsigned long long> pairRangeOfJob(int jobs, int jobInd, bool shardOnly) const;
   void queuePair(unsigned hapRowA, unsigned hapRowB);
   void closeBatch(bool last);
   void flush();

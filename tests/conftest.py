@@ -19,7 +19,7 @@ def wave_group_member(K):
     forced = os.environ.get("FSMC_DIAG_W2_MEMBER")  # (A/B runs of another member: the library honours the same variable)
     if forced:
         nw, kh = (int(x) for x in forced.split("x"))
-        if nw * kh >= K:
+        if nw * kh >= K and ((nw - 1) * kh < K or (kh == 48 and 2 * kh < K)):  # (the library's condition: w2Member)
             return (nw, kh)
     return ((4, 48) if K <= 192 else (4, 64) if K <= 256 else (4, 80) if K <= 320 else (6, 64) if K <= 384
             else (7, 64) if K <= 448 else (8, 64))
