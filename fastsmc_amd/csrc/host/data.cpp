@@ -300,11 +300,12 @@ Data::Data(const DecodingParams& params)
   haploidSampleSize = sampleSize * 2ul;
   siteWasFlippedDuringFolding.assign(static_cast<size_t>(sites), false);
 
+  // (Data.cpp:62-70 seeds the process-global generator; here the object's own, util.hpp)
   if (params.useKnownSeed) {
-    std::srand(1234u);
+    rng.seed(1234u);
   } else {
     std::random_device rd;
-    std::srand(rd());
+    rng.seed(rd());
   }
   setupJobWindows(params.jobInd, params.jobs);
   readSamplesList(root, params.jobInd, params.jobs);
@@ -790,10 +791,10 @@ Data Data::fromArrays(const uint8_t* alleles, size_t nHaps, size_t nSites, const
   d.chrNumber = chrNumber;
   d.siteWasFlippedDuringFolding.assign(nSites, false);
   if (useKnownSeed) {
-    std::srand(1234u);
+    d.rng.seed(1234u);
   } else {
     std::random_device rd;
-    std::srand(rd());
+    d.rng.seed(rd());
   }
   d.setupJobWindows(1, 1);
   for (size_t i = 0; i < nHaps / 2; ++i) {
@@ -870,7 +871,7 @@ std::vector<Individual> Data::individuals() const
 std::vector<std::vector<int>> Data::calculateUndistinguishedCounts(const int numCsfsSamples) const
 {
   // Data.cpp:567-599.  A draw shuffles a vector of totalSamples - 2 entries with a generator seeded from std::rand()
-  // (Data.cpp:144-160): 3 x sites shuffles of cohort size -- 3 G element moves at the 10 000-haplotype x 100 000-site
+  // (Data.cpp:144-160; here the object's own glibc-compatible generator: util.hpp, GlibcRand): 3 x sites shuffles of cohort size -- 3 G element moves at the 10 000-haplotype x 100 000-site
   // shape.  Only the SEEDS depend on each other (the std::rand() sequence, in site and `distinguished` order, drawn only
   // where the reference draws): they are taken sequentially, the shuffles then run on every host core.
   const size_t n = derivedAlleleCounts.size();
@@ -898,7 +899,7 @@ std::vector<std::vector<int>> Data::calculateUndistinguishedCounts(const int num
       if (successes < 0 || successes > totalSamples - 2) {
         undistinguished[i][static_cast<size_t>(distinguished)] = -1; // (no draw: Data.cpp:146-148)
       } else {
-        draws.push_back(Draw{static_cast<uint32_t>(i), distinguished, std::rand()});
+        draws.push_back(Draw{static_cast<uint32_t>(i), distinguished, rng.next()});
       }
     }
   }

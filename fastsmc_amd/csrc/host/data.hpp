@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "decoding_params.hpp"
+#include "util.hpp"
 
 namespace fsmc_host
 {
@@ -87,6 +88,9 @@ public:
 
   // packed genotypes of the individuals this job loaded: row 2*ind + (hap-1)
   std::vector<uint64_t> bits;
+  // the generator the emission preparation draws its seeds from (the reference: the process's rand(), seeded in the
+  // constructor, Data.cpp:62-70; here the object's own -- same numbers, not perturbed by other threads' rand() calls)
+  mutable GlibcRand rng;
   size_t wordsPerHap = 0;
 
 private:

@@ -7,7 +7,17 @@
 namespace fsmc_host
 {
 
-ASMC::ASMC(DecodingParams params) : mParams(std::move(params)), mHmm(Data(mParams), mParams) {}
+namespace
+{
+// (in the member-initialiser list, before Data reads the files: the device comes up while the host parses)
+DecodingParams withDeviceStarting(DecodingParams p)
+{
+  warmUpDevice(p.gpuDevice);
+  return p;
+}
+} // namespace
+
+ASMC::ASMC(DecodingParams params) : mParams(withDeviceStarting(std::move(params))), mHmm(Data(mParams), mParams) {}
 
 ASMC::ASMC(const std::string& inFileRoot, const std::string& decodingQuantFile, const std::string& outFileRoot)
     : mParams(inFileRoot, decodingQuantFile, outFileRoot.empty() ? inFileRoot : outFileRoot, 1, 1, "array", false,
@@ -60,10 +70,11 @@ void ASMC::decodePairs(const std::vector<std::string>& hapIdsA, const std::vecto
   decodePairs(a, b, perPairPosteriors, sumOfPosteriors, perPairPosteriorMeans, perPairMAPs);
 }
 
-FastSMC::FastSMC(DecodingParams params) : mParams(std::move(params)), mHmm(Data(mParams), mParams) {}
+FastSMC::FastSMC(DecodingParams params) : mParams(withDeviceStarting(std::move(params))), mHmm(Data(mParams), mParams) {}
 
 FastSMC::FastSMC(const std::string& inFileRoot, const std::string& outFileRoot)
-    : mParams(inFileRoot, inFileRoot + ".decodingQuantities.gz", outFileRoot, true), mHmm(Data(mParams), mParams)
+    : mParams(withDeviceStarting(DecodingParams(inFileRoot, inFileRoot + ".decodingQuantities.gz", outFileRoot, true))),
+      mHmm(Data(mParams), mParams)
 {
 }
 

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstdio>
 #include <chrono>
+#include <future>
+#include <mutex>
 #include <cmath>
 #include <iomanip>
 #include <limits>
@@ -543,9 +545,43 @@ void HMM::resetDecoding()
   }
 }
 
+// The first HIP call of a process initialises the runtime (0.15 s on the GPU box: most of what FastSMC.run() spent
+// before its kernel was in flight).  The drivers start it on a helper thread BEFORE they read their input files -- a
+// context is created and destroyed, which leaves the runtime up -- and the first real engine() waits for that thread.
+// Without a device the attempt fails quietly; the error surfaces where the engine is actually needed.
+namespace
+{
+std::mutex gWarmMutex;
+std::shared_future<void> gWarm;
+} // namespace
+
+void warmUpDevice(int device)
+{
+  std::lock_guard<std::mutex> lock(gWarmMutex);
+  if (gWarm.valid()) {
+    return;
+  }
+  gWarm = std::async(std::launch::async, [device] {
+            fsmc_ctx* c = nullptr;
+            if (fsmc_ctx_create(device, nullptr, &c) == FSMC_OK) {
+              fsmc_ctx_destroy(c);
+            }
+          }).share();
+}
+
 fsmc_ctx* HMM::engine()
 {
   if (!mCtx) {
+    {
+      std::shared_future<void> warm;
+      {
+        std::lock_guard<std::mutex> lock(gWarmMutex);
+        warm = gWarm;
+      }
+      if (warm.valid()) {
+        warm.wait();
+      }
+    }
     int rc = fsmc_ctx_create(mParams.gpuDevice, nullptr, &mCtx);
     if (rc != FSMC_OK) {
       mCtx = nullptr;

@@ -233,6 +233,9 @@ private:
   std::vector<float> mExpectedCoalTimes;
 };
 
+// starts the HIP runtime's initialisation on a helper thread (drivers: before the input files are read); HMM::engine() waits
+void warmUpDevice(int device);
+
 // HMM.cpp:43-61: second column of an intervals file ("intervalStart expectedCoalescentTime intervalEnd" per line)
 std::vector<float> readExpectedTimesFromIntervalsFile(const std::string& fileName);
 bool isRegularFile(const std::string& path);

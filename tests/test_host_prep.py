@@ -68,6 +68,35 @@ def test_prepared_model_options(small_problem, opts):
     _assert_same_model(hmm.preparedModel(), want)
 
 
+def test_emission_preparation_ignores_other_threads_calling_rand(small_problem):
+    """The reference seeds the PROCESS's rand() in Data's constructor and draws the emission preparation's seeds from it in
+    HMM's (Data.cpp:62-70, 144-160).  Another thread that calls rand() in between shifts that sequence -- the HIP runtime
+    does while it initialises, on the drivers' helper thread.  A Data object carries its own glibc-compatible generator:
+    with a thread hammering libc's rand() the prepared model is still the oracle's (which calls the real generator)."""
+    import ctypes
+    import threading
+
+    libc = ctypes.CDLL(None)
+    stop = threading.Event()
+
+    def hammer():
+        while not stop.is_set():
+            for _ in range(1000):
+                libc.rand()
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    try:
+        sp = small_problem
+        for _ in range(3):
+            data = api.Data.from_arrays(sp["haps"].alleles, sp["haps"].bp, sp["haps"].cm, True, True)
+            hmm = api.HMM(data, api.decoding_quantities_from_tables(sp["tables"]), _params())
+            _assert_same_model(hmm.preparedModel(), sp["model"])
+    finally:
+        stop.set()
+        t.join()
+
+
 def test_file_readers_round_trip(small_problem, tmp_path):
     """.hap.gz/.samples/.map + .decodingQuantities.gz written by synth, read by the C++ host
     (FastSMC-mode readers, Data.cpp:98-141, 397-565; parser DecodingQuantities.cpp:60-345)."""

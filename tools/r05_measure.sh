@@ -23,11 +23,12 @@ if [ $PART = round ] || [ $PART = all ]; then
   python3 tools/measure_configs.py k320 k350 k402 k448 k500 k600 > gpurun_out/round_r05/wide_beyond_256.jsonl 2> gpurun_out/round_r05/wide_beyond_256.err
   echo "round done"
 fi
-if [ $PART = extra ] || [ $PART = all ]; then
+if [ $PART = extra ] || [ $PART = extra_nopmc ] || [ $PART = all ]; then
+  mkdir -p gpurun_out/round_r05
   # round 5: the consumers of a small launch with two waves per window and on the one-wave kernels (C1 shape), the C1
   # launch's counters (a wave alone on its SIMD), the product path's timeline, the allocation-cost curve
   python3 tools/measure_configs.py c1_consumers > gpurun_out/round_r05/c1_consumers.jsonl 2> gpurun_out/round_r05/c1_consumers.err
-  bash tools/prof_counters.sh r05_c1_lone_wave --workload c1 > gpurun_out/r05_pmc_c1.log 2>&1
+  if [ $PART != extra_nopmc ]; then bash tools/prof_counters.sh r05_c1_lone_wave --workload c1 > gpurun_out/r05_pmc_c1.log 2>&1; fi
   FSMC_HOST_TIMING=1 python3 tools/measure_configs.py run_c2 > gpurun_out/round_r05/run_c2_timeline.json 2> gpurun_out/round_r05/run_c2_timeline.err
   python3 tools/malloc_cost.py > gpurun_out/round_r05/malloc_cost.txt 2>&1
   python3 bench.py --workload c1 --mode sums --steps 10 --warmup 2 --cpu-pairs 0 > gpurun_out/round_r05/c1_sums_bench.json 2> gpurun_out/round_r05/c1_sums_bench.err
