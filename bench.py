@@ -8,7 +8,7 @@ FASTSMC_EXAMPLE shape C1 as IBD decode and as sum over pairs, and the 256-state 
 context that runs on the library's default workspace policy (`config.library_default_workspace`).
 
 N > 1 (one process per GPU under torch.distributed.run; BASELINE.json configs[2], "C3"): STRONG scaling of ONE
-problem -- synthetic 10000 haplotypes x 100000 sites, 69 states, a fixed seeded sub-list of 2^20 of the 49 995 000
+problem -- synthetic 10000 haplotypes x 100000 sites, 69 states, a fixed seeded sub-list of 5 * 2^19 = 2 621 440 of the 49 995 000
 pairs in the reference's enumeration order.  The work list is cut into contiguous shards of equal pair-site weight
 (whole 64-pair groups: the reference's own job decomposition, HMM.cpp:310-321), every rank holds the model and the
 packed haplotypes, there is no collective on the data path, and the variable-length IBD records are gathered to
@@ -40,7 +40,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); ~6.3e12 is the measured achievable
 METRIC = "haplotype-pairs decoded/sec (whole node) + GB/s vs HBM roofline, 69-state HMM"
-C3_PAIRS = 1 << 20
+# 40 960 groups of 64 pairs = 20 rounds of one GPU's 2048 resident waves; at N = 8 a GPU's share is 2.5 rounds -- NOT a
+# whole number (a list of 2^20 pairs gave every GPU exactly one round at N = 8: no tail, a flattering curve)
+C3_PAIRS = 5 << 19
 C3_SEED = 20260
 PROFILE_ROUND = "r05"  # profiles/<round>_traffic.json, <round>_c3_n1.json: the committed measurements of this build
 
@@ -376,7 +378,7 @@ def main() -> None:
                          "order (fastsmc_amd.dist.reduce_sums: the reference's PosteriorMerger order)")
     ap.add_argument("--haps", type=int, default=0, help="haplotypes (default: the workload's)")
     ap.add_argument("--sites", type=int, default=0, help="sites (default: the workload's)")
-    ap.add_argument("--pairs", type=int, default=0, help="c3: pairs in the seeded sub-list (default 2^20)")
+    ap.add_argument("--pairs", type=int, default=0, help="c3: pairs in the seeded sub-list (default 5 * 2^19)")
     ap.add_argument("--states", type=int, default=69)
     ap.add_argument("--chunk-sites", type=int, default=0, help="sites between beta checkpoints (0 = automatic)")
     ap.add_argument("--beta-stride", type=int, default=0,
