@@ -297,17 +297,23 @@ template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half,
     return seq ? decode_kernel<KT, kModePerPair, false, true, false>
                : decode_kernel<KT, kModePerPair, false, false, false>;
   case kModeSums:
+    if constexpr (halfBuilt(KT)) {
+      if (half && !seq) {
+        return decode_kernel<KT, kModeSums, false, false, true>;
+      }
+    }
     return seq ? decode_kernel<KT, kModeSums, false, true, false> : decode_kernel<KT, kModeSums, false, false, false>;
   default:
     return nullptr;
   }
 }
 
-// Beta stride 2 (every second beta row stored, the others recomputed in the alpha sweep): array-mode IBD decode of
-// the family members it is built for.
+// Beta stride 2 (every second beta row stored, the others recomputed in the alpha sweep): array-mode IBD decode and
+// array-mode sums over pairs (round 5: at size the sums moved 8K bytes a pair-site at the rate the CUs' path to memory
+// delivers -- the IBD decode's situation before stride 2) of the family members it is built for.
 bool halfAvailable(int mode, const fsmc_model* m)
 {
-  return mode == kModeIbd && !m->sequence && halfBuilt(familyMember(m));
+  return (mode == kModeIbd || mode == kModeSums) && !m->sequence && halfBuilt(familyMember(m));
 }
 
 // The wide-model kernel with lane = pair and several waves per group (fsmc_kernels_w2.h): 128 < K <= 512, every
@@ -420,7 +426,7 @@ KernelFn pickKernel(int mode, bool track, const fsmc_model* m, bool dual = false
     return nullptr;
   }
   const bool half = halfAvailable(mode, m) && m->ctx->betaStride != 1; // (also with two half-groups per wave)
-  if (mode == kModeIbd) {
+  if (mode == kModeIbd || mode == kModeSums) {
     m->ctx->lastStride = half ? 2 : 1;
   }
   const int member = familyMember(m);
@@ -676,7 +682,8 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   // one chunk buffer, the checkpoints and the parking rows goes to such chunks (array-mode IBD decode of the
   // lane-per-pair family, one group per wave: the paired kernel is not built with them).
   size_t resident = 0;
-  if (maxChunks > 1 && mode == kModeIbd && !m->sequence && !w2 && !paired && !anyStates(m) && ctx->residentChunks != 0) {
+  if (maxChunks > 1 && (mode == kModeIbd || mode == kModeSums) && !m->sequence && !w2 && !paired && !anyStates(m) &&
+      ctx->residentChunks != 0) {
     const size_t rowsBudget = rowsSoft;
     // (exactly the rows of plan.wsSlot below: a plan must qualify again for the buffer it was given -- with a row of
     //  slack here a context whose soft budget is the buffer it holds lost one resident chunk at its next launch)
@@ -2087,9 +2094,26 @@ int fsmc_decode_sums_batches(fsmc_ctx* ctx, const fsmc_model* m, const uint32_t*
   }
   FSMC_HIP(ctx, hipSetDevice(ctx->device));
   KernelFn fn = pickKernel(kModeSums, false, m);
+  bool strideForced = false;
+  if (fn && ctx->betaStride == 0 && ctx->lastStride == 2) {
+    // Beta stride 2 pays where the launch fills the chip (C2: 2762 -> 2454 ms: the rows' traffic was the bound); a wave
+    // alone on its SIMD only gets the recomputed half sweep on top (C1 shape: 41.2 -> 43.3 ms).  Left to itself
+    // (fsmc_ctx_set_beta_stride 0) a launch of fewer batches than the chip holds waves keeps stride 1 -- the kernel AND
+    // its plan (planLaunch reads the same setting).
+    int blocksPerCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, fn, (int)blockThreads(kModeSums, m), 0) == hipSuccess &&
+        blocksPerCU >= 1 && n_batches < (size_t)ctx->nCU * (size_t)std::min(blocksPerCU, 8)) {
+      ctx->betaStride = 1;
+      strideForced = true;
+      fn = pickKernel(kModeSums, false, m);
+    }
+  }
   LaunchPlan plan;
   earnWorkspace(ctx, m, kModeSums);
   rc = planLaunch(ctx, m, kModeSums, fn, plan);
+  if (strideForced) {
+    ctx->betaStride = 0;
+  }
   if (rc != FSMC_OK) {
     return rc;
   }

@@ -61,7 +61,8 @@ constexpr bool halfBuilt(const int KT)
   X(KT, kModeSums, false, true, false)
 #define FSMC_KT_HALF_KERNELS(X, KT)                                                                                    \
   X(KT, kModeIbd, true, false, true)                                                                                   \
-  X(KT, kModeIbd, false, false, true)
+  X(KT, kModeIbd, false, false, true)                                                                                  \
+  X(KT, kModeSums, false, false, true)
 
 #define FSMC_DECLARE_KT(KT, MODE, TRACK, SEQ, HALF)                                                                    \
   extern template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);

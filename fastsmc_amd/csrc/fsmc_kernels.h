@@ -1031,7 +1031,8 @@ constexpr int minWavesPerSimd(const int KT)
 template <int KT, int MODE, bool TRACK, bool SEQ, bool HALF, bool DUAL = false>
 __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(const KParams p)
 {
-  static_assert(!HALF || (!SEQ && MODE == kModeIbd), "beta stride 2 is built for the array-mode IBD decode");
+  static_assert(!HALF || (!SEQ && (MODE == kModeIbd || MODE == kModeSums)),
+                "beta stride 2 is built for the array-mode IBD decode and the array-mode sums over pairs");
   static_assert(KT > 0 && KT <= kMaxStates, "a member of the kernel family (fsmc_instances.h)");
   static_assert(!DUAL || (MODE == kModeIbd && !SEQ), "two half-groups per wave: array-mode IBD");
   // array mode: the backward loops are rotated (operand-free step tails overlap the next step's first operand requests)
@@ -1070,8 +1071,9 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   // p.residentChunks extra chunk buffers per wave) pass B keeps them and pass A sweeps those chunks without rebuilding
   // them: the same rows, bit for bit (the rebuild repeats pass B's operations on the same operands).
   float4* const resBase = saveS + vecF4;
-  // (array-mode IBD decode, one group per wave: the paired kernel is chunked too, but keeps no resident chunks)
-  constexpr bool kResidentBuilt = !SEQ && !DUAL && MODE == kModeIbd;
+  // (array-mode IBD decode and sums over pairs, one group per wave: the paired kernel is chunked too, but keeps no
+  //  resident chunks)
+  constexpr bool kResidentBuilt = !SEQ && !DUAL && (MODE == kModeIbd || MODE == kModeSums);
   const int nResident = kResidentBuilt ? p.residentChunks : 0;
   const int C = p.chunk;
   // per-state posterior sums of the open segments (TRACK), one column per lane.  They live in the wave's workspace --

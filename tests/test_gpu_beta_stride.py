@@ -108,3 +108,54 @@ def test_stride_is_validated(small_problem):
     with pytest.raises(capi.FsmcError):
         ctx.set_beta_stride(3)
     ctx.close()
+
+
+@pytest.mark.parametrize("K_time", [(69, 50), (50, 50), (33, 200), (100, 200)])
+def test_sums_over_pairs_with_both_strides_and_resident_chunks(small_problem, K_time):
+    """The sums over pairs have beta stride 2 and resident chunks too (round 5: at size they moved 8K bytes a pair-site
+    at the rate the CUs' path to memory delivers).  The one-wave kernel (two-wave windows switched off): strides 1 and 2,
+    whole windows and the checkpoint / rebuild layout with 0, 1 and every chunk resident, the 00 / 01 / 11 split, a
+    ragged batch -- every variant the oracle's sums, bit for bit."""
+    from fastsmc_amd import synth
+
+    K, time = K_time
+    if K == 69:
+        pm, bits, folded = small_problem["model"], small_problem["bits"], small_problem["folded"]
+    else:
+        tables = synth.make_model_tables(K)
+        haps = synth.make_haps(64, 333, seed=5, cm_per_mb=25.0, switch_per_cm=0.6)
+        bits, derived, flipped = synth.fold_and_pack(haps.alleles)
+        folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+        pm = O.prepare_model(tables, (haps.cm / 100.0).astype(np.float32), haps.bp, derived, 64, time=time)
+    pairs = O.enumerate_all_pairs(32)[:151]
+    want = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
+    for b0 in range(0, len(pairs), 64):
+        sub = pairs[b0:b0 + 64]
+        ob = np.stack([folded[a] ^ folded[b] for a, b in sub])
+        hb = np.stack([folded[a] & folded[b] for a, b in sub])
+        post, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
+        O.augment_sum_over_pairs(pm, post, len(sub), ob, hb, *want)
+    seen = set()
+    for stride in (1, 2):
+        for limit, chunk, resident in ((0, 0, -1), (1 << 30, 48, 0), (1 << 30, 48, 1), (1 << 30, 48, -1), (1 << 30, 47, -1)):
+            ctx = capi.Context(0)
+            ctx.set_two_wave_windows(1)
+            ctx.set_beta_stride(stride)
+            if limit:
+                ctx.set_workspace_limit(limit)
+            if chunk:
+                ctx.set_chunk_sites(chunk)
+            ctx.set_resident_chunks(resident)
+            model = ctx.create_model(pm)
+            ctx.upload_haps(bits, pm.S)
+            ctx.upload_worklist(_pairs_array(pairs), capi.whole_sequence_groups(len(pairs), pm.S))
+            s, mm = ctx.decode_sums(model, major_minor=True)
+            assert ctx.last_beta_stride() == stride and ctx.last_waves_per_window() == 1
+            seen.add((stride, ctx.info()["max_chunks"] > 1, ctx.last_resident_chunks()))
+            s_only, _ = ctx.decode_sums(model)
+            ctx.close()
+            np.testing.assert_array_equal(s, want[0], err_msg=f"stride {stride} chunk {chunk} resident {resident}")
+            for got, w in zip(mm, want[1:]):
+                np.testing.assert_array_equal(got, w)
+            np.testing.assert_array_equal(s_only, want[0])
+    assert any(c and r == 0 for _, c, r in seen) and any(c and r > 1 for _, c, r in seen) and any(not c for _, c, _ in seen)
