@@ -297,7 +297,7 @@ template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half,
     return seq ? decode_kernel<KT, kModePerPair, false, true, false>
                : decode_kernel<KT, kModePerPair, false, false, false>;
   case kModeSums:
-    if constexpr (halfBuilt(KT)) {
+    if constexpr (halfSumsBuilt(KT)) {
       if (half && !seq) {
         return decode_kernel<KT, kModeSums, false, false, true>;
       }
@@ -313,7 +313,8 @@ template <int KT> KernelFn pickMember(int mode, bool track, bool seq, bool half,
 // delivers -- the IBD decode's situation before stride 2) of the family members it is built for.
 bool halfAvailable(int mode, const fsmc_model* m)
 {
-  return (mode == kModeIbd || mode == kModeSums) && !m->sequence && halfBuilt(familyMember(m));
+  const int member = familyMember(m);
+  return !m->sequence && ((mode == kModeIbd && halfBuilt(member)) || (mode == kModeSums && halfSumsBuilt(member)));
 }
 
 // The wide-model kernel with lane = pair and several waves per group (fsmc_kernels_w2.h): 128 < K <= 512, every

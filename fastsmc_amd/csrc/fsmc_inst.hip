@@ -15,6 +15,9 @@ FSMC_DEFINE_KT_DUAL(FSMC_INSTANCE_KT)
 // (every member of the library is built with beta stride 2 as well: halfBuilt(), fsmc_instances.h)
 static_assert(halfBuilt(FSMC_INSTANCE_KT), "not a member of the library: add it to FSMC_ALL_KT or FSMC_EXACT_KT");
 FSMC_KT_HALF_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
+#if FSMC_INSTANCE_KT != 50 // (halfSumsBuilt, fsmc_instances.h)
+FSMC_KT_HALF_SUMS_KERNELS(FSMC_DEFINE_KT, FSMC_INSTANCE_KT)
+#endif
 FSMC_DEFINE_KT_DUAL_HALF(FSMC_INSTANCE_KT)
 #elif defined(FSMC_INSTANCE_W2)
 #ifndef FSMC_INSTANCE_NW

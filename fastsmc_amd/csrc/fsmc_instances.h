@@ -42,10 +42,19 @@ constexpr bool exactMember(const int KT)
   return KT == 69 FSMC_EXACT_KT(FSMC_IS_EXACT_TERM);
 }
 
+// The sums over pairs with beta stride 2: every member that has stride 2 EXCEPT the exact 50-state one, whose
+// instantiation the compiler builds with an operand block spilled while its scalar load is in flight
+// (tools/check_inflight_sgprs.py: v_writelane of the load's destination before the wait) -- it keeps stride 1.
+constexpr bool halfSumsBuilt(const int KT);
 // beta stride 2 needs three K-vectors in a lane's registers: built for the members it fits
 constexpr bool halfBuilt(const int KT)
 {
   return KT == 16 || KT == 32 || KT == 48 || KT == 64 || KT == 80 || KT == 96 || KT == 112 || KT == 128 || exactMember(KT);
+}
+
+constexpr bool halfSumsBuilt(const int KT)
+{
+  return halfBuilt(KT) && KT != 50;
 }
 
 #define FSMC_KT_KERNELS(X, KT)                                                                                         \
@@ -61,8 +70,9 @@ constexpr bool halfBuilt(const int KT)
   X(KT, kModeSums, false, true, false)
 #define FSMC_KT_HALF_KERNELS(X, KT)                                                                                    \
   X(KT, kModeIbd, true, false, true)                                                                                   \
-  X(KT, kModeIbd, false, false, true)                                                                                  \
-  X(KT, kModeSums, false, false, true)
+  X(KT, kModeIbd, false, false, true)
+// ... and the sums over pairs with beta stride 2 (round 5), where the instantiation passes the in-flight check
+#define FSMC_KT_HALF_SUMS_KERNELS(X, KT) X(KT, kModeSums, false, false, true)
 
 #define FSMC_DECLARE_KT(KT, MODE, TRACK, SEQ, HALF)                                                                    \
   extern template __global__ void decode_kernel<KT, MODE, TRACK, SEQ, HALF>(const KParams);
@@ -115,22 +125,25 @@ FSMC_ALL_KT(FSMC_DECLARE_MEMBER)
   FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT)                                                                                  \
   FSMC_KT_BIDIR_KERNELS(FSMC_DECLARE_KT_BIDIR, KT)                                                                      \
   FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, KT)                                                                             \
+  FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, KT)                                                                        \
   FSMC_DECLARE_KT_DUAL_HALF(KT)                                                                                         \
   FSMC_DECLARE_KT_DUAL(KT)
 FSMC_EXACT_KT(FSMC_DECLARE_EXACT_MEMBER)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 16)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 32)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 48)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 64)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 69)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 96)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 112)
-FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 128)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 16) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 16)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 32) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 32)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 48) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 48)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 64) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 64)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 69) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 69)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 80) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 80)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 96) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 96)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 112) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 112)
+FSMC_KT_HALF_KERNELS(FSMC_DECLARE_KT, 128) FSMC_KT_HALF_SUMS_KERNELS(FSMC_DECLARE_KT, 128)
 FSMC_DECLARE_KT_DUAL_HALF(16)
 FSMC_DECLARE_KT_DUAL_HALF(32)
 FSMC_DECLARE_KT_DUAL_HALF(48)
 FSMC_DECLARE_KT_DUAL_HALF(64)
 FSMC_DECLARE_KT_DUAL_HALF(69)
+FSMC_DECLARE_KT_DUAL_HALF(80)
 FSMC_DECLARE_KT_DUAL_HALF(96)
 FSMC_DECLARE_KT_DUAL_HALF(112)
 FSMC_DECLARE_KT_DUAL_HALF(128)

@@ -54,9 +54,6 @@ __global__ __launch_bounds__(2 * kWave, minWavesPerSimd(KT)) void decode_kernel_
   __shared__ float4 emisLdsAll[2][2][NC * E4A];
   __shared__ float4 landLdsAll[2][kLandF4];
   __shared__ unsigned groupLds;
-#if defined(FSMC_BIDIR_OWN_TILE) // (diagnostic: the sums' transposition tile in LDS of its own)
-  __shared__ float tileOwn[2][MODE == kModeSums ? KA * 65 : 1];
-#endif
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: wave A (forward), 1: wave B (backward)
@@ -276,19 +273,11 @@ __global__ __launch_bounds__(2 * kWave, minWavesPerSimd(KT)) void decode_kernel_
       if (MODE == kModeSums) {
         // HMM::augmentSumOverPairs (HMM.cpp:1052-1081), as in fsmc_kernels.h: the K x 64 tile transposed through the
         // landing zone, lane j owns state j (and j + 64), the pairs of the batch added in batch order
-#if defined(FSMC_BIDIR_OWN_TILE)
-        float* const tile = tileOwn[wave];
-#else
         float* const tile = reinterpret_cast<float*>(&landLdsAll[wave][0]);
-#endif
         unsigned char* const cls = reinterpret_cast<unsigned char*>(&emisLdsAll[wave][freeSlot][0]);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-#if defined(FSMC_BIDIR_DEBUG_VEC) // (diagnostic: the carried vector itself instead of the posterior)
-          tile[k * 65 + lane] = v[k];
-#else
           tile[k * 65 + lane] = w[k] * cq;
-#endif
         }
         if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
           cls[lane] = (unsigned char)c;
@@ -460,10 +449,6 @@ __global__ __launch_bounds__(2 * kWave, minWavesPerSimd(KT)) void decode_kernel_
         // everything requested so far has landed: this site's emission rows (requested two sites ago) and beta row
         // (requested behind the combine of the site before)
         waitVm0();
-#if defined(FSMC_BIDIR_SLEEP)
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-#endif
         __builtin_amdgcn_wave_barrier();
         if (__builtin_expect(pos == from, 0)) {
           alpha_init<KT, KA>(K, v, tPi, e);
@@ -499,10 +484,6 @@ __global__ __launch_bounds__(2 * kWave, minWavesPerSimd(KT)) void decode_kernel_
       for (int pos = mid - 1; pos >= from; --pos) {
         const int q = pos + 1;
         waitVm0(); // the rows of site q (requested an iteration ago) and alpha of site pos have landed
-#if defined(FSMC_BIDIR_SLEEP)
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-#endif
         __builtin_amdgcn_wave_barrier();
         const int c = obsClass(q);
         beta_step_pk<KT, KA, true, kGhost<KT>>(v, w, rowSetOf<KT>(tabs, stepRowOf(q)), &emisLdsAll[wave][q & 1][c * E4],

@@ -143,10 +143,12 @@ int fsmc_ctx_expect_work(fsmc_ctx* ctx, double pair_sites, int32_t states);
 /* Tuning: sites between beta checkpoints when a decode window does not fit the workspace (0 = automatic:
  * max(512, ceil(sqrt(window))), 2048 for the wave-group kernel, rounded up to 16).  Results do not depend on it. */
 int fsmc_ctx_set_chunk_sites(fsmc_ctx* ctx, uint32_t sites);
-/* Tuning: beta stride of the IBD decode.  1 = every beta row of a chunk goes through HBM (8K bytes per pair-site);
- * 2 = every second row does and the alpha sweep recomputes the others from their successor (4K bytes per
- * pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (array mode, K <= 128), else 1.
- * Results do not depend on it.  fsmc_ctx_last_beta_stride reports what the last IBD launch used. */
+/* Tuning: beta stride of the IBD decode and of the sums over pairs.  1 = every beta row of a chunk goes through HBM
+ * (8K bytes per pair-site); 2 = every second row does and the alpha sweep recomputes the others from their successor
+ * (4K bytes per pair-site, half a sweep more arithmetic); 0 = automatic: 2 where that kernel exists (array mode,
+ * K <= 128) -- for the sums only when the launch has at least as many batches as the chip holds waves (a wave alone on
+ * its SIMD only gets the recomputed half sweep on top) --, else 1.  Results do not depend on it.
+ * fsmc_ctx_last_beta_stride reports what the last IBD or sums launch used. */
 int fsmc_ctx_set_beta_stride(fsmc_ctx* ctx, uint32_t stride);
 int fsmc_ctx_last_beta_stride(const fsmc_ctx* ctx, int32_t* stride);
 /* How the last launch was laid out: sites per chunk (= the longest window when every beta row fitted), chunks per

@@ -150,7 +150,8 @@ def test_sums_over_pairs_with_both_strides_and_resident_chunks(small_problem, K_
             ctx.upload_haps(bits, pm.S)
             ctx.upload_worklist(_pairs_array(pairs), capi.whole_sequence_groups(len(pairs), pm.S))
             s, mm = ctx.decode_sums(model, major_minor=True)
-            assert ctx.last_beta_stride() == stride and ctx.last_waves_per_window() == 1
+            # (the exact 50-state member has no stride-2 sums: its instantiation fails the in-flight check, fsmc_instances.h)
+            assert ctx.last_beta_stride() == (stride if K != 50 else 1) and ctx.last_waves_per_window() == 1
             seen.add((stride, ctx.info()["max_chunks"] > 1, ctx.last_resident_chunks()))
             s_only, _ = ctx.decode_sums(model)
             ctx.close()
