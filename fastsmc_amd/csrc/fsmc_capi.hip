@@ -464,13 +464,6 @@ KernelFn pickBidirKernel(int mode, const fsmc_model* m)
   if (m->sequence || anyStates(m) || waveGroups(mode, m)) {
     return nullptr;
   }
-  // The 128-state member (models of 113 ... 128 states) keeps one wave a window: its two-wave instantiations hold part of
-  // a K-vector in scratch memory, and the per-pair consumer's results did not reproduce from run to run on the GPU
-  // (tests/test_gpu_two_wave_windows.py at 128 states; every other member is bit-equal to the one-wave kernel and to
-  // itself).  Not understood; not shipped.
-  if (familyMember(m) == 128) {
-    return nullptr;
-  }
   switch (familyMember(m)) {
 #define FSMC_PICK_BIDIR(KTX)                                                                                            \
   case KTX:                                                                                                            \

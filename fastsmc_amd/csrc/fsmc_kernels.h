@@ -1054,6 +1054,9 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   // through it with a row stride of 65 floats
   constexpr int kLandF4 = (MODE == kModeSums && (KA * 65 + 3) / 4 > K4A * kWave) ? (KA * 65 + 3) / 4 : K4A * kWave;
   __shared__ float4 betaLds[kLandF4];
+  // kModePerPair: the expected coalescence times (read in the consumer's loop over the states; as scalar loads they
+  // were K values live at once -- fsmc_kernels_bidir.h, same place)
+  __shared__ float coalLds[MODE == kModePerPair ? KA : 1];
 
   const int lane = threadIdx.x;
   const cfloat_p tPi = (cfloat_p)p.pi, tCR = (cfloat_p)p.cR, tExpT = (cfloat_p)p.expT;
@@ -1096,6 +1099,13 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
   struct EmisRegs {
     float4 v[NL];
   };
+  if (MODE == kModePerPair) {
+    for (int k = lane; k < K; k += kWave) {
+      coalLds[k] = (k < Kreal) ? p.expCoal[k] : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 
   for (unsigned round = 0;; ++round) {
 #if defined(FSMC_DIAG_GROUP_TIMES)
@@ -1800,14 +1810,13 @@ __global__ __launch_bounds__(kWave, minWavesPerSimd(KT)) void decode_kernel(cons
         if (MODE == kModePerPair) {
           // HMM::writePerPairOutput (HMM.cpp:1378-1409): mean = sum_k post*E[t_k] (k ascending from 0.f),
           // MAP = first strictly larger posterior
-          const cfloat_p tCoal = (cfloat_p)p.expCoal;
           float mean = 0.f;
           float best = 0.f;
           int arg = 0;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const float post = w[k] * cq;
-            mean = mean + post * tCoal[k];
+            mean = mean + post * coalLds[k];
             if (best < post) {
               arg = k;
               best = post;

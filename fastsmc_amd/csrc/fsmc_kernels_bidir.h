@@ -54,9 +54,19 @@ __global__ __launch_bounds__(2 * kWave, minWavesPerSimd(KT)) void decode_kernel_
   __shared__ float4 emisLdsAll[2][2][NC * E4A];
   __shared__ float4 landLdsAll[2][kLandF4];
   __shared__ unsigned groupLds;
+  // kModePerPair: the expected coalescence times, read from LDS in the consumer's loop over the states.  (As scalar loads --
+  // one per state, all live at once: hundreds of spilled scalars -- the 128-state member's instantiation of this kernel
+  // returned wrong and, with several groups, irreproducible means; with the times in LDS it is bit-equal like the others.)
+  __shared__ float coalLds[MODE == kModePerPair ? KA : 1];
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: wave A (forward), 1: wave B (backward)
+  if (MODE == kModePerPair) {
+    for (int k = threadIdx.x; k < K; k += 2 * kWave) {
+      coalLds[k] = (k < (kGhost<KT> ? p.K : K)) ? p.expCoal[k] : 0.f;
+    }
+    __syncthreads();
+  }
   // This wave's LDS is always addressed as emisLdsAll[wave][...] / landLdsAll[wave][...], straight off the __shared__
   // arrays: through a pointer VARIABLE (float4* land = landLdsAll[wave]) the accesses go through a generic-to-LDS address
   // cast whose null check this compiler folds wrongly in some instantiations -- one member's requests landed at wrong LDS
@@ -243,14 +253,13 @@ __global__ __launch_bounds__(2 * kWave, minWavesPerSimd(KT)) void decode_kernel_
     // slot whose rows are no longer needed (the sums' 00 / 01 / 11 split parks the classes of the 64 pairs there).
     auto consume = [&](const int pos, const float cq, const int c, const int freeSlot) {
       if (MODE == kModePerPair) { // HMM.cpp:1378-1409
-        const cfloat_p tCoal = (cfloat_p)p.expCoal;
         float mean = 0.f;
         float best = 0.f;
         int arg = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const float post = w[k] * cq;
-          mean = mean + post * tCoal[k];
+          mean = mean + post * coalLds[k];
           if (best < post) {
             arg = k;
             best = post;

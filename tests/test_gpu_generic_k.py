@@ -67,7 +67,7 @@ def test_generic_kernel_matches_oracle(K):
         np.testing.assert_array_equal(mean, wmean)
         np.testing.assert_array_equal(mp, wmap)
         s, _ = ctx.decode_sums(model)  # (K = 256 included: the transposition tile is sized for it)
-        assert ctx.last_waves_per_window() == (2 if K <= 112 and two_wave == 0 else 1)
+        assert ctx.last_waves_per_window() == (2 if K <= 128 and two_wave == 0 else 1)
         assert ctx.last_kernel() == _member(K)
         wsum = np.zeros((pm.S, pm.K), np.float32)
         O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)

@@ -25,9 +25,9 @@ def _pairs_array(pairs):
     return np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
 
 
-@pytest.mark.parametrize("K", [69, 50, 16, 33, 64, 80, 81, 99, 100, 112, 128])
+@pytest.mark.parametrize("K", [69, 50, 16, 33, 64, 80, 81, 99, 100, 112, 120, 128])
 def test_whole_windows_every_consumer(K):
-    two = 2 if K <= 112 else 1  # (the 128-state member keeps one wave a window: csrc/fsmc_capi.hip, pickBidirKernel)
+    two = 2
     pm, bits, folded = _problem(K)
     pairs = O.enumerate_all_pairs(32)[:151]  # 64 + 64 + 23
     pr = _pairs_array(pairs)
