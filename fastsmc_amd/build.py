@@ -24,11 +24,25 @@ KT_MEMBERS = [16, 32, 48, 64, 69, 80, 96, 112, 128]
 # of 16, each <= 128 states); the list is part of the library's source hash.
 EXACT_MEMBERS = sorted(set(int(x) for x in os.environ.get("FSMC_EXACT_MEMBERS", "50 100").split()))  # (a member once)
 # wave-group kernel: (states per wave, waves per group) -- csrc/fsmc_instances.h, FSMC_ALL_W2
-W2_MEMBERS = [(48, 4), (64, 4), (80, 4), (64, 6), (64, 7), (64, 8)]
+W2_MEMBERS = [(48, 4), (64, 4), (80, 4), (64, 6), (64, 7), (64, 8), (80, 8), (96, 8), (128, 8)]
 
 
 def w2_unit_name(kh: int, nw: int) -> str:
     return f"w2_{kh}" if nw == 4 else f"w2_{kh}x{nw}"
+
+
+def w2_units() -> list[tuple[str, list[str]]]:
+    """(unit name, -D switches) of the wave-group kernel's translation units: one per member, two (array mode, sequence
+    mode) for the members beyond 512 states, whose ten kernels take minutes to compile."""
+    out = []
+    for kh, nw in W2_MEMBERS:
+        defs = [f"-DFSMC_INSTANCE_W2={kh}", f"-DFSMC_INSTANCE_NW={nw}"]
+        if kh * nw > 512:
+            out.append((w2_unit_name(kh, nw), defs + ["-DFSMC_INSTANCE_SEQ=0"]))
+            out.append((w2_unit_name(kh, nw) + "_seq", defs + ["-DFSMC_INSTANCE_SEQ=1"]))
+        else:
+            out.append((w2_unit_name(kh, nw), defs))
+    return out
 OBJ_DIR = os.path.join(CSRC, "obj")
 
 
@@ -75,7 +89,7 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     srcs = hip_sources()
     os.makedirs(OBJ_DIR, exist_ok=True)
     stamp = os.path.join(OBJ_DIR, "members.txt")  # (another list of exact members is another library)
-    members = " ".join(str(k) for k in KT_MEMBERS + EXACT_MEMBERS + [w2_unit_name(*m) for m in W2_MEMBERS])
+    members = " ".join(str(k) for k in KT_MEMBERS + EXACT_MEMBERS + [n for n, _ in w2_units()])
     if not force and _newer(HIP_LIB, srcs) and os.path.exists(stamp) and open(stamp).read() == members:
         return HIP_LIB
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + exact_define() + ["-c"]
@@ -86,13 +100,12 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
              ("idseeds", os.path.join(CSRC, "fsmc_identify_seeds.hip"), [])]
     units += [(f"kt{k}", os.path.join(CSRC, "fsmc_inst.hip"), [f"-DFSMC_INSTANCE_KT={k}"])
               for k in KT_MEMBERS + EXACT_MEMBERS]
-    units += [(w2_unit_name(kh, nw), os.path.join(CSRC, "fsmc_inst.hip"),
-               [f"-DFSMC_INSTANCE_W2={kh}", f"-DFSMC_INSTANCE_NW={nw}"]) for kh, nw in W2_MEMBERS]
+    units += [(name, os.path.join(CSRC, "fsmc_inst.hip"), defs) for name, defs in w2_units()]
     # longest first (the wide members take a minute or more each, the small ones seconds): the queue's tail is short
     def cost(u):
         if u[0].startswith("w2_"):
-            kh, _, nw = u[0][3:].partition("x")
-            return 1000 + int(kh) * int(nw or 4)
+            kh, _, nw = u[0][3:].replace("_seq", "").partition("x")
+            return 1000 + int(kh) * int(nw or 4) + (1 if u[0].endswith("_seq") else 0)
         return int(u[0][2:]) if u[0][2:].isdigit() else 60
     units.sort(key=cost, reverse=True)
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))

@@ -339,7 +339,8 @@ W2Member w2Member(int K)
   if (const char* v = std::getenv("FSMC_DIAG_W2_MEMBER")) {
     int nw = 0, kh = 0;
     // (a member whose waves the model fills all but the last of, or the 48-state one: where the kernel masks ghosts)
-    if (std::sscanf(v, "%dx%d", &nw, &kh) == 2 && nw * kh >= K && ((nw - 1) * kh < K || (kh == 48 && 2 * kh < K))) {
+    if (std::sscanf(v, "%dx%d", &nw, &kh) == 2 && nw * kh >= K &&
+        ((nw - 1) * kh < K || (kh == 48 && 2 * kh < K) || (nw * kh > 512 && (nw - 2) * kh < K))) {
 #define FSMC_IS_W2(KHX, NWX)                                                                                            \
   if (kh == KHX && nw == NWX) {                                                                                        \
     return {nw, kh};                                                                                                   \
@@ -353,7 +354,11 @@ W2Member w2Member(int K)
   if (K <= 320) return {4, 80};
   if (K <= 384) return {6, 64};
   if (K <= 448) return {7, 64};
-  return {8, 64};
+  if (K <= 512) return {8, 64};
+  // beyond 512 states: eight waves without landing zones (fsmc_kernels_w2.h, LAND)
+  if (K <= 640) return {8, 80};
+  if (K <= 768) return {8, 96};
+  return {8, 128};
 }
 
 template <int KH, int NW, bool SEQ> KernelFn pickWaveGroupKernelOf(int mode, bool track)

@@ -1,7 +1,7 @@
 // fsmc_inst.hip -- one family member's kernel instantiations (see fsmc_instances.h).
 // Compiled with -DFSMC_INSTANCE_KT=<n> (lane-per-pair member) or -DFSMC_INSTANCE_W2=<n> (states per wave of the
-// wave-group kernel; -DFSMC_INSTANCE_NW=<waves per group>, four if not given); fastsmc_amd/build.py drives one hipcc
-// per member, in parallel.
+// wave-group kernel; -DFSMC_INSTANCE_NW=<waves per group>, four if not given; -DFSMC_INSTANCE_SEQ=0|1: only the array-mode /
+// sequence-mode kernels of the member); fastsmc_amd/build.py drives one hipcc per unit, in parallel.
 #include "fsmc_instances.h"
 
 namespace fsmc
@@ -23,7 +23,13 @@ FSMC_DEFINE_KT_DUAL_HALF(FSMC_INSTANCE_KT)
 #ifndef FSMC_INSTANCE_NW
 #define FSMC_INSTANCE_NW 4
 #endif
+#if !defined(FSMC_INSTANCE_SEQ)
 FSMC_W2_KERNELS(FSMC_DEFINE_W2, FSMC_INSTANCE_W2, FSMC_INSTANCE_NW)
+#elif FSMC_INSTANCE_SEQ
+FSMC_W2_MODE_KERNELS(FSMC_DEFINE_W2, FSMC_INSTANCE_W2, FSMC_INSTANCE_NW, true)
+#else
+FSMC_W2_MODE_KERNELS(FSMC_DEFINE_W2, FSMC_INSTANCE_W2, FSMC_INSTANCE_NW, false)
+#endif
 #else
 #error "define FSMC_INSTANCE_KT or FSMC_INSTANCE_W2"
 #endif

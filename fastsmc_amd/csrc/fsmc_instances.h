@@ -97,17 +97,14 @@ constexpr bool halfSumsBuilt(const int KT)
   template __global__ void decode_kernel<KT, kModeIbd, true, false, true, true>(const KParams);                      \
   template __global__ void decode_kernel<KT, kModeIbd, false, false, true, true>(const KParams);
 // NW waves per group of KH states each, lane = pair (fsmc_kernels_w2.h): 128 < K <= 512
-#define FSMC_W2_KERNELS(X, KH, NW)                                                                                     \
-  X(KH, kModeIbd, true, false, NW)                                                                                     \
-  X(KH, kModeIbd, false, false, NW)                                                                                    \
-  X(KH, kModeDump, false, false, NW)                                                                                   \
-  X(KH, kModeSums, false, false, NW)                                                                                   \
-  X(KH, kModePerPair, false, false, NW)                                                                                \
-  X(KH, kModeIbd, true, true, NW)                                                                                      \
-  X(KH, kModeIbd, false, true, NW)                                                                                     \
-  X(KH, kModeDump, false, true, NW)                                                                                    \
-  X(KH, kModeSums, false, true, NW)                                                                                    \
-  X(KH, kModePerPair, false, true, NW)
+#define FSMC_W2_MODE_KERNELS(X, KH, NW, SEQ)                                                                           \
+  X(KH, kModeIbd, true, SEQ, NW)                                                                                       \
+  X(KH, kModeIbd, false, SEQ, NW)                                                                                      \
+  X(KH, kModeDump, false, SEQ, NW)                                                                                     \
+  X(KH, kModeSums, false, SEQ, NW)                                                                                     \
+  X(KH, kModePerPair, false, SEQ, NW)
+// (array mode and sequence mode: one translation unit, or -- -DFSMC_INSTANCE_SEQ=0|1, the widest members -- one each)
+#define FSMC_W2_KERNELS(X, KH, NW) FSMC_W2_MODE_KERNELS(X, KH, NW, false) FSMC_W2_MODE_KERNELS(X, KH, NW, true)
 #define FSMC_DECLARE_W2(KH, MODE, TRACK, SEQ, NW)                                                                      \
   extern template __global__ void decode_kernel_w2<KH, MODE, TRACK, SEQ, NW>(const KParams);
 #define FSMC_DEFINE_W2(KH, MODE, TRACK, SEQ, NW)                                                                       \
@@ -115,7 +112,7 @@ constexpr bool halfSumsBuilt(const int KT)
 
 // every member of the library (build.py compiles fsmc_inst.hip once for each entry of these two lists)
 #define FSMC_ALL_KT(Y) Y(16) Y(32) Y(48) Y(64) Y(69) Y(80) Y(96) Y(112) Y(128)
-#define FSMC_ALL_W2(Y) Y(48, 4) Y(64, 4) Y(80, 4) Y(64, 6) Y(64, 7) Y(64, 8)
+#define FSMC_ALL_W2(Y) Y(48, 4) Y(64, 4) Y(80, 4) Y(64, 6) Y(64, 7) Y(64, 8) Y(80, 8) Y(96, 8) Y(128, 8)
 
 #if !defined(FSMC_INSTANCE_KT) && !defined(FSMC_INSTANCE_W2)
 #define FSMC_DECLARE_MEMBER(KT) FSMC_KT_KERNELS(FSMC_DECLARE_KT, KT) FSMC_KT_BIDIR_KERNELS(FSMC_DECLARE_KT_BIDIR, KT)

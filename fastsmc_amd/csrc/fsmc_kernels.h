@@ -40,7 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMaxStates = 256; // the widest model a lane-per-pair or two-workgroups-per-CU member decodes (fsmc_instances.h)
-constexpr int kMaxStatesW2 = 512; // ... and the wave-group kernel with one workgroup per CU (four waves of 80 states, six to eight of 64)
+constexpr int kMaxStatesW2 = 1024; // ... and the wave-group kernel with one workgroup per CU (four waves of 80 states, six to eight of 64;
+                                    // beyond 512 states eight waves of 80 / 96 / 128 without landing zones)
 constexpr int kMaxStatesAny = 4096; // ... and the any-K kernel (fsmc_kernels_any.h: K-vectors in the workspace)
 
 enum Mode : int { kModeIbd = 0, kModeDump = 1, kModePerPair = 2, kModeSums = 3 };

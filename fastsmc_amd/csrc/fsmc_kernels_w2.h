@@ -313,7 +313,9 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
   // (An instantiation WITHOUT any mask for models that fill every wave -- config 4's 256 = 4 x 64 states -- was built and
   //  measured in round 5: 3 % SLOWER at size and 8 % on 3000-site windows, interleaved on one box: the allocator's luck,
   //  not the instruction count, decides this kernel.  Not kept.)
-  constexpr bool kMasked = KH == 48 ? (2 * H >= NW) : (H == NW - 1);
+  // (the members of more than 512 states -- eight waves of 80 / 96 / 128 -- serve every model that fills all but their last
+  //  TWO waves: 513 ... 560 states leave the seventh of eight 80-state waves with ghosts too)
+  constexpr bool kMasked = KH == 48 ? (2 * H >= NW) : (KP > 512 ? H >= NW - 2 : H == NW - 1);
   auto ascending = [&](auto blockStates, const float blIn, const bool first) {
     constexpr int BS = decltype(blockStates)::value;
     constexpr int NB = KH / BS;
@@ -782,7 +784,13 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
   constexpr int E4H = NC * ERS;      // float4 of one site's emission values of this wave's states (+ padding)
   constexpr int NLE = (E4H + kWave - 1) / kWave;
   __shared__ float4 emisLds[NW][2][E4H];       // [wave][ring slot][class * K4H + k4]
-  __shared__ float4 betaLds[NW][K4H * kWave];  // [wave]: landing zone of the next site's beta row (its part)
+  // Members of more than 512 states (eight waves of 80 ... 128) have NO landing zones -- a group's beta row alone would be
+  // the CU's LDS: the combine reads the row from the workspace into registers instead (behind the forward step, its
+  // latency in the open), and the sums consumer transposes its tile 32 states a turn.
+  constexpr bool LAND = KP <= 512;
+  constexpr int kTileStates = LAND ? KH : 32; // kModeSums: states of a turn through the tile
+  constexpr int kLandF4 = LAND ? K4H * kWave : (MODE == kModeSums ? kTileStates * kWave / 4 : 1);
+  __shared__ float4 betaLds[NW][kLandF4];      // [wave]: landing zone of the next site's beta row (its part)
   __shared__ float mailLds[W2Rows<NW>::Mail * kWave];
   __shared__ float4 piLds[KP / 4];   // initialStateProb, zero padded
   __shared__ float4 coalLds[MODE == kModePerPair ? KP / 4 : 1]; // kModePerPair: expected coalescence times, zero padded
@@ -960,12 +968,14 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
       }
     };
     auto fetchBeta = [&](const float4* row) {
-      const gchar_p base = uniformPtr(row + halfF4);
+      if constexpr (LAND) {
+        const gchar_p base = uniformPtr(row + halfF4);
 #pragma unroll
-      for (int k4 = 0; k4 < K4H; ++k4) {
+        for (int k4 = 0; k4 < K4H; ++k4) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_global_load_lds(rowSlot(base, k4, laneOff), &betaLds[h][k4 * kWave], 16, 0, 2 /* nt */);
+          __builtin_amdgcn_global_load_lds(rowSlot(base, k4, laneOff), &betaLds[h][k4 * kWave], 16, 0, 2 /* nt */);
 #endif
+        }
       }
     };
     // beta at the last site of the window: all ones, scaled (HMM.cpp:887-897): 1.0f / K for a state of the model
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
           // this site's beta row is requested during the step (RowIO): the combine of the site before has released the
           // landing zone.  (The chunk's first row was requested in front of the loop: its step requests it once more,
           // the same bytes.  The sums consumer transposes its tile through the zone and requests the next row itself.)
-          if constexpr (MODE != kModeSums) {
+          if constexpr (MODE != kModeSums && LAND) {
             const RowIO in = {uniformPtr(chunkbuf + (size_t)(pos - lo) * vecF4 + halfF4), laneOff, &betaLds[h][0]};
             FSMC_W2_ROLE(h, (alpha_step_w2<NW, KH, H, true, true>(cx, a, w, rsp, tCR, e, cycW, in)));
           } else {
@@ -1246,7 +1256,17 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
         //  landing-zone reads first -- a third K-vector of registers, and part of alpha went to scratch memory.  What
         //  orders a block's reads behind the products of the block before is an empty asm statement that takes those
         //  products as operands and clobbers memory; a scheduling barrier alone does not bind instruction selection)
-        {
+        if constexpr (!LAND) {
+          // no landing zone: this wave's part of the row out of the workspace (w is free between the step and the combine)
+          loadHalf(chunkbuf + (size_t)(pos - lo) * vecF4, w);
+#pragma unroll
+          for (int k = 0; k < KH; k += 2) {
+            const f32x2 av = {a[k], a[k + 1]}, bv = {w[k], w[k + 1]};
+            const f32x2 q = pmul(av, bv);
+            w[k] = q.x;
+            w[k + 1] = q.y;
+          }
+        } else {
           constexpr int kCB4 = 4; // float4 per block
           float4 cb[kCB4], nb[kCB4];
 #pragma unroll
@@ -1304,73 +1324,85 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
           // pairs in batch order (local fp32 sum from 0.f).  Every wave transposes the tile of ITS states through its
           // landing zone (64 x 64 floats, row k rotated by k lanes: conflict-free both ways); lane j then owns state j.
           float* const tile = reinterpret_cast<float*>(&betaLds[h][0]);
-#pragma unroll
-          for (int k = 0; k < KH; ++k) {
-            tile[k * kWave + ((lane + k) & (kWave - 1))] = w[k] * cq;
-          }
           if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
             clsLds[h][lane] = (unsigned char)c;
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          waitLgkm0();
-          __builtin_amdgcn_wave_barrier();
-          // lane j owns state j of every 64 of this wave's states (a wave of more than 64 states takes two turns)
+          // (a member without landing zones: kTileStates states a turn through a tile of that many rows)
 #pragma unroll
-          for (int base = 0; base < KH; base += kWave) {
-            const int kLocal = base + lane;
-            const int state = h * KH + kLocal;
-            if (kLocal < KH && state < K) {
-              float* acc = p.sums + (size_t)blockIdx.x * p.sumsSlot + (size_t)pos * K + state;
-              float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
-              if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
-                if (p.flags & FSMC_WANT_SUMS) s = acc[0];
-                if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                  s00 = acc[p.sumsPlane];
-                  s01 = acc[2 * p.sumsPlane];
-                  s11 = acc[3 * p.sumsPlane];
-                }
+          for (int t0 = 0; t0 < KH; t0 += kTileStates) {
+            if (t0 > 0) { // the walk of the turn before has read the tile
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              waitLgkm0();
+              __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int k = 0; k < kTileStates; ++k) {
+              if (t0 + k < KH) {
+                tile[k * kWave + ((lane + k) & (kWave - 1))] = w[t0 + k] * cq;
               }
-              // (sixteen pairs a turn: their tile values are read together, then added in batch order; the 00 / 01 /
-              //  11 split adds +0.f to the sums a pair does not belong to -- fsmc_kernels.h, same place)
-              auto walk = [&](auto splitTag) {
-                constexpr bool SPLIT = decltype(splitTag)::value;
-                constexpr int kWalk = 16;
-                auto add = [&](const float q, const int cv) {
-                  s = s + q;
-                  if constexpr (SPLIT) { // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
-                    s11 = s11 + (cv == 2 ? q : 0.f);
-                    s00 = s00 + (cv == 1 ? q : 0.f);
-                    s01 = s01 + (cv == 0 ? q : 0.f);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            waitLgkm0();
+            __builtin_amdgcn_wave_barrier();
+            // lane j owns state j of every 64 of the turn's states (a wave of more than 64 states takes two rounds)
+#pragma unroll
+            for (int base = 0; base < kTileStates; base += kWave) {
+              const int kTile = base + lane;    // row of the tile
+              const int kLocal = t0 + kTile;     // state of this wave
+              const int state = h * KH + kLocal;
+              if (kTile < kTileStates && kLocal < KH && state < K) {
+                float* acc = p.sums + (size_t)blockIdx.x * p.sumsSlot + (size_t)pos * K + state;
+                float s = 0.f, s00 = 0.f, s01 = 0.f, s11 = 0.f;
+                if (round > 0) { // a later group of the batch: the running sums of the pairs before (this wave wrote them)
+                  if (p.flags & FSMC_WANT_SUMS) s = acc[0];
+                  if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                    s00 = acc[p.sumsPlane];
+                    s01 = acc[2 * p.sumsPlane];
+                    s11 = acc[3 * p.sumsPlane];
+                  }
+                }
+                // (sixteen pairs a turn: their tile values are read together, then added in batch order; the 00 / 01 /
+                //  11 split adds +0.f to the sums a pair does not belong to -- fsmc_kernels.h, same place)
+                auto walk = [&](auto splitTag) {
+                  constexpr bool SPLIT = decltype(splitTag)::value;
+                  constexpr int kWalk = 16;
+                  auto add = [&](const float q, const int cv) {
+                    s = s + q;
+                    if constexpr (SPLIT) { // 0 het -> 01, 1 hom major -> 00, 2 hom minor -> 11
+                      s11 = s11 + (cv == 2 ? q : 0.f);
+                      s00 = s00 + (cv == 1 ? q : 0.f);
+                      s01 = s01 + (cv == 0 ? q : 0.f);
+                    }
+                  };
+                  int v = 0;
+                  for (; v + kWalk <= nPairsInGroup; v += kWalk) {
+                    float q[kWalk];
+                    int cv[kWalk];
+#pragma unroll
+                    for (int i = 0; i < kWalk; ++i) {
+                      q[i] = tile[kTile * kWave + ((v + i + kTile) & (kWave - 1))];
+                      cv[i] = SPLIT ? (int)clsLds[h][v + i] : 0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < kWalk; ++i) {
+                      add(q[i], cv[i]);
+                    }
+                  }
+                  for (; v < nPairsInGroup; ++v) {
+                    add(tile[kTile * kWave + ((v + kTile) & (kWave - 1))], SPLIT ? (int)clsLds[h][v] : 0);
                   }
                 };
-                int v = 0;
-                for (; v + kWalk <= nPairsInGroup; v += kWalk) {
-                  float q[kWalk];
-                  int cv[kWalk];
-#pragma unroll
-                  for (int i = 0; i < kWalk; ++i) {
-                    q[i] = tile[kLocal * kWave + ((v + i + kLocal) & (kWave - 1))];
-                    cv[i] = SPLIT ? (int)clsLds[h][v + i] : 0;
-                  }
-#pragma unroll
-                  for (int i = 0; i < kWalk; ++i) {
-                    add(q[i], cv[i]);
-                  }
+                if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                  walk(std::true_type{});
+                } else {
+                  walk(std::false_type{});
                 }
-                for (; v < nPairsInGroup; ++v) {
-                  add(tile[kLocal * kWave + ((v + kLocal) & (kWave - 1))], SPLIT ? (int)clsLds[h][v] : 0);
+                if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
+                if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
+                  acc[p.sumsPlane] = s00;
+                  acc[2 * p.sumsPlane] = s01;
+                  acc[3 * p.sumsPlane] = s11;
                 }
-              };
-              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                walk(std::true_type{});
-              } else {
-                walk(std::false_type{});
-              }
-              if (p.flags & FSMC_WANT_SUMS) acc[0] = s;
-              if (p.flags & FSMC_WANT_MAJOR_MINOR_SUMS) {
-                acc[p.sumsPlane] = s00;
-                acc[2 * p.sumsPlane] = s01;
-                acc[3 * p.sumsPlane] = s11;
               }
             }
           }

@@ -19,21 +19,23 @@ def wave_group_member(K):
     forced = os.environ.get("FSMC_DIAG_W2_MEMBER")  # (A/B runs of another member: the library honours the same variable)
     if forced:
         nw, kh = (int(x) for x in forced.split("x"))
-        if nw * kh >= K and ((nw - 1) * kh < K or (kh == 48 and 2 * kh < K)):  # (the library's condition: w2Member)
+        if nw * kh >= K and ((nw - 1) * kh < K or (kh == 48 and 2 * kh < K)
+                             or (nw * kh > 512 and (nw - 2) * kh < K)):  # (the library's condition: w2Member)
             return (nw, kh)
     return ((4, 48) if K <= 192 else (4, 64) if K <= 256 else (4, 80) if K <= 320 else (6, 64) if K <= 384
-            else (7, 64) if K <= 448 else (8, 64))
+            else (7, 64) if K <= 448 else (8, 64) if K <= 512 else (8, 80) if K <= 640 else (8, 96) if K <= 768
+            else (8, 128))
 
 
 def expected_member(K):
-    """What fsmc_ctx_last_kernel reports: the exact or padded family member for K <= 128; up to 512 states the
-    wave-group kernel (1000 + states per wave with four waves a group, 1000 * waves + 64 with more); beyond, 0 = the
-    any-K kernel (a pair's K-vectors in the workspace)."""
+    """What fsmc_ctx_last_kernel reports: the exact or padded family member for K <= 128; up to 1024 states the
+    wave-group kernel (1000 + states per wave with four waves a group, 1000 * waves + states per wave with more);
+    beyond, 0 = the any-K kernel (a pair's K-vectors in the workspace)."""
     if K in (69, 50, 100):  # the exact members of the default build (fsmc_instances.h: FSMC_EXACT_KT)
         return K
     if K <= 128:
         return (K + 15) // 16 * 16
-    if K > 512:
+    if K > 1024:
         return 0
     nw, kh = wave_group_member(K)
     return 1000 + kh if nw == 4 else 1000 * nw + kh

@@ -32,7 +32,8 @@ def _stride(K):
 
 
 @pytest.mark.parametrize("K", [2, 5, 16, 17, 33, 49, 50, 51, 64, 65, 70, 80, 81, 99, 100, 101, 128, 130, 192, 200, 256, 257, 300, 320, 321,
-                               384, 385, 402, 448, 449, 512, 513, 520])
+                               384, 385, 402, 448, 449, 512, 513, 520, 560, 561, 600, 640, 641, 700, 768, 769, 1000, 1024,
+                               1025])
 def test_generic_kernel_matches_oracle(K):
     pm, bits, folded = _problem(K)
     pairs = O.enumerate_all_pairs(32)[:96]
@@ -72,7 +73,7 @@ def test_generic_kernel_matches_oracle(K):
         wsum = np.zeros((pm.S, pm.K), np.float32)
         O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
         np.testing.assert_array_equal(s, wsum)
-        if K in (5, 100, 200, 256, 300, 402, 520):  # the 00 / 01 / 11 split in one member of each kernel
+        if K in (5, 100, 200, 256, 300, 402, 520, 700, 1000, 1025):  # the 00 / 01 / 11 split in one member of each kernel
             s2, mm = ctx.decode_sums(model, major_minor=True)
             want = [np.zeros((pm.S, pm.K), np.float32) for _ in range(4)]
             O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, want[0], want[1], want[2], want[3])
@@ -137,8 +138,8 @@ def test_wide_model_scan_thresholds_that_reach_the_upper_waves(K, time):
 
 
 def test_too_many_states_is_rejected():
-    """Up to 512 states a kernel holds a pair's vectors in registers; beyond, the any-K kernel keeps them in the workspace
-    (tested above: 513 and 520 states); the library's limit is 4096."""
+    """Up to 1024 states a kernel holds a pair's vectors in registers; beyond, the any-K kernel keeps them in the workspace
+    (tested above: 1025 states); the library's limit is 4096."""
     pm, bits, _ = _problem(16)
     ctx = capi.Context(0)
     import copy
@@ -152,10 +153,10 @@ def test_too_many_states_is_rejected():
     ctx.close()
 
 
-@pytest.mark.parametrize("K", [300, 350, 402, 500, 530])
+@pytest.mark.parametrize("K", [300, 350, 402, 500, 530, 600, 700, 900, 1030])
 def test_beyond_256_states_windows_chunks_and_thresholds(K):
     """Models of more than 256 states -- 300: the wave-group kernel with four waves of 80 states; 350, 402, 500: six,
-    seven, eight waves of 64; 530: the any-K kernel -- through the checkpoint / rebuild layout (explicit chunk lengths that do and do not
+    seven, eight waves of 64; 530, 600 / 700 / 900: eight waves of 80 / 96 / 128 without landing zones; 1030: the any-K kernel -- through the checkpoint / rebuild layout (explicit chunk lengths that do and do not
     divide the windows), windows whose scan ends before the decode window does, one- and two-site windows, ragged
     groups, with and without segment ages, and a time threshold that puts the scan's state threshold beyond 256 (the
     scan's sum then walks several waves of a group)."""

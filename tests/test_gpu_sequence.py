@@ -128,7 +128,7 @@ def test_per_pair_and_sums(gpu, seq_problem):
         np.testing.assert_array_equal(got, w)
 
 
-@pytest.mark.parametrize("K", [12, 100, 150, 200, 256, 260, 340, 400, 460, 520])
+@pytest.mark.parametrize("K", [12, 100, 150, 200, 256, 260, 340, 400, 460, 520, 650, 800, 1030])
 def test_generic_k_sequence(K):
     tables = synth.make_model_tables(K)
     haps = synth.make_haps(64, 150, seed=5, cm_per_mb=1.2, bp_per_site=2500, switch_per_cm=2.0)
@@ -144,7 +144,7 @@ def test_generic_k_sequence(K):
     groups = capi.whole_sequence_groups(len(pairs), pm.S)
     _assert_records_equal(ctx.decode_ibd(model, _pairs_array(pairs), groups),
                           O.decode_pairs_ibd(pm, folded, pairs, batch_size=64))
-    if K > 128:  # the wave-group kernel up to 512 states, the any-K kernel beyond, also in sequence mode
+    if K > 128:  # the wave-group kernel up to 1024 states, the any-K kernel beyond, also in sequence mode
         assert ctx.last_kernel() == expected_member(K)
     ctx.upload_worklist(_pairs_array(pairs), groups)
     post = ctx.decode_posteriors(model)
@@ -165,7 +165,7 @@ def test_generic_k_sequence(K):
         np.testing.assert_array_equal(s_, wsum)
         ctx.set_chunk_sites(32)
         nw, kh = wave_group_member(K)
-        row_bytes = (nw * kh if K <= 512 else (K + 15) // 16 * 16) * 256
+        row_bytes = (nw * kh if K <= 1024 else (K + 15) // 16 * 16) * 256
         ctx.set_workspace_limit(60 * row_bytes * 2)  # ~60 rows for each of the two groups: 150 sites do not fit
         _assert_records_equal(ctx.decode_ibd(model, _pairs_array(pairs), groups),
                               O.decode_pairs_ibd(pm, folded, pairs, batch_size=64))

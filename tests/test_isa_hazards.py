@@ -26,13 +26,13 @@ def test_no_instruction_touches_a_scalar_load_in_flight(tmp_path):
     sys.path.insert(0, ROOT)
     from concurrent.futures import ThreadPoolExecutor
 
-    from fastsmc_amd.build import EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, W2_MEMBERS, exact_define, w2_unit_name
+    from fastsmc_amd.build import EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, exact_define, w2_units
 
     flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + exact_define()
     jobs = [(ROOT, flags, f"-DFSMC_INSTANCE_KT={k}", str(tmp_path / f"kt{k}.s")) for k in KT_MEMBERS + EXACT_MEMBERS]
     # (the wave-group kernel uses the same operand loads)
-    jobs += [(ROOT, flags, f"-DFSMC_INSTANCE_W2={kh} -DFSMC_INSTANCE_NW={nw}", str(tmp_path / (w2_unit_name(kh, nw) + ".s")))
-             for kh, nw in W2_MEMBERS]
+    jobs += [(ROOT, flags, " ".join(defs), str(tmp_path / (name + ".s"))) for name, defs in w2_units()]
+    jobs.sort(key=lambda j: ("INSTANCE_W2" not in j[2], j[2]))  # (the wave-group units take longest: first)
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
         outs = list(ex.map(_compile_member, jobs))
     sys.path.insert(0, os.path.join(ROOT, "tools"))

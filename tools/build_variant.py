@@ -22,8 +22,8 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from fastsmc_amd.build import (CSRC, EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, OBJ_DIR, W2_MEMBERS,  # noqa: E402
-                               exact_define, w2_unit_name)
+from fastsmc_amd.build import (CSRC, EXACT_MEMBERS, HIPCC_FLAGS, KT_MEMBERS, OBJ_DIR, exact_define,  # noqa: E402
+                               w2_units)
 
 
 def main():
@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--src-dir", default=CSRC)
     ap.add_argument("--resources", default="")
     ap.add_argument("--units", default="", help="comma-separated unit names (kt112, w2_64x6 ...): only these are recompiled")
+    ap.add_argument("--extra-w2", default="", help="wave-group members beyond the shipped ones, '128x4,128x3' (states per "
+                    "wave x waves): compiled from --src-dir, whose fsmc_instances.h must list them in FSMC_ALL_W2")
     args = ap.parse_args(argv)
     out_dir = os.path.join(ROOT, "fastsmc_amd", "variants")
     obj = os.path.join(out_dir, "obj_" + args.name)
@@ -46,7 +48,9 @@ def main():
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + exact_define() + extra
     inst = os.path.join(args.src_dir, "fsmc_inst.hip")
     kt = [(f"kt{k}", inst, [f"-DFSMC_INSTANCE_KT={k}"]) for k in KT_MEMBERS + EXACT_MEMBERS]
-    w2 = [(w2_unit_name(kh, nw), inst, [f"-DFSMC_INSTANCE_W2={kh}", f"-DFSMC_INSTANCE_NW={nw}"]) for kh, nw in W2_MEMBERS]
+    w2 = [(name, inst, defs) for name, defs in w2_units()]
+    extra_w2 = [tuple(int(x) for x in e.split("x")) for e in args.extra_w2.split(",") if e]
+    extra_w2 = [(f"w2_{kh}x{nw}", inst, [f"-DFSMC_INSTANCE_W2={kh}", f"-DFSMC_INSTANCE_NW={nw}"]) for kh, nw in extra_w2]
     rest = [("idsort", os.path.join(args.src_dir, "fsmc_identify_sort.hip"), []),
             ("idseeds", os.path.join(args.src_dir, "fsmc_identify_seeds.hip"), [])]
     capi = [("capi", os.path.join(args.src_dir, "fsmc_capi.hip"), [])]
@@ -56,6 +60,7 @@ def main():
     if args.units:
         want = set(args.units.split(","))
         units = [u for u in kt + w2 + rest + capi if u[0] in want]
+    units = units + extra_w2
     names = {u[0] for u in units}
 
     def compile_unit(u):
