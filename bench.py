@@ -304,12 +304,14 @@ def other_workloads(ctx, capi, flags: int, budget_s: float) -> list:
     allocated already): C1 = the FASTSMC_EXAMPLE shape (300 haplotypes x 6760 sites, K = 69, all 44 850 pairs) as IBD
     decode, as sum over pairs (the reference's published ASMC regression job, time_regression.py), as per-pair mean +
     MAP rows and -- its first 8192 pairs: 4K B of output per pair-site -- as full posterior dump (ASMC.decodePairs,
-    ASMC.cpp:80-128), with the CPU port timed on the same shape; C4 = 256 states x 200 000-site windows on a
+    ASMC.cpp:80-128), with the CPU port timed on the same shape; a 600-state model on the 600 x 3000 list (179 700 pairs:
+    the wave-group kernel's eight waves of 80 states, no landing zones); C4 = 256 states x 200 000-site windows on a
     256-haplotype sub-cohort (32 640 pairs: 510 groups = ONE round of the 512 resident workgroups) and on a 512-haplotype
     one (130 816 pairs: 2044 groups = four rounds).  Not part of `value`."""
     out = []
     t_begin = time.perf_counter()
     for name, (n_hap, n_sites, K), modes in (("c1", (300, 6760, 69), ("ibd", "sums", "per_pair", "dump")),
+                                             ("k600_list", (600, 3000, 600), ("ibd",)),
                                              ("c4", (256, 200000, 256), ("ibd",)),
                                              ("c4_four_rounds", (512, 200000, 256), ("ibd",))):
         if time.perf_counter() - t_begin > budget_s:

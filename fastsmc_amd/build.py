@@ -125,6 +125,9 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = Non
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB, *objs], check=True, cwd=ROOT)
+    for f in os.listdir(OBJ_DIR):  # objects of units the library no longer has (tools/build_variant.py links what is here)
+        if f.endswith(".o") and os.path.join(OBJ_DIR, f) not in objs:
+            os.remove(os.path.join(OBJ_DIR, f))
     open(stamp, "w").write(members)
     return HIP_LIB
 

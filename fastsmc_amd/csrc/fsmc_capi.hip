@@ -317,16 +317,21 @@ bool halfAvailable(int mode, const fsmc_model* m)
   return !m->sequence && ((mode == kModeIbd && halfBuilt(member)) || (mode == kModeSums && halfSumsBuilt(member)));
 }
 
-// The wide-model kernel with lane = pair and several waves per group (fsmc_kernels_w2.h): 128 < K <= 512, every
+// The wide-model kernel with lane = pair and several waves per group (fsmc_kernels_w2.h): 128 < K <= 1024, every
 // consumer, array and sequence mode.  fsmc_model_create picks the member (w2Member) and pads such a model's rows to
-// KP = waves x states per wave: four waves of 48 or 64 (two workgroups per CU) or 80 states, six to eight waves of 64.
+// KP = waves x states per wave: four waves of 48 or 64 (two workgroups per CU) or 80 states, six to eight waves of 64,
+// eight waves of 80 / 96 / 128 beyond 512 states.
 bool waveGroups(int mode, const fsmc_model* m)
 {
   return m->w2NW > 0 && (mode == kModeIbd || mode == kModeDump || mode == kModeSums || mode == kModePerPair);
 }
 
 // Member of the wave-group kernel for a model of K states: {waves per group, states per wave}.  Up to 320 states four
-// waves (48, 64: two workgroups per CU; 80: one, with the whole register file); beyond, six to eight waves of 64 states.
+// waves (48, 64: two workgroups per CU; 80: one, with the whole register file); beyond, six to eight waves of 64 states;
+// beyond 512 states eight waves of 80 / 96 / 128 states, which have no landing zones for the beta row (they would not
+// fit the CU's LDS) and hold part of their vectors in scratch memory (round 5: K = 600 0.03 -> 0.28 of the roofline).
+// (Three / four waves of 128 states for 321 ... 512 states were measured too: 1.5 x slower than six / eight of 64,
+// profiles/r05_w2_wide_members_of_128.txt.)
 // (Measured on the 600 x 3000 list, profiles/r04_wide_members_ab.txt: five waves of 64 are 6 % slower than four of 80
 // at 300 / 320 states; four waves of 96 / 112 states -- round 4's first members for 321 ... 448 states, which keep part
 // of their vectors in scratch memory -- 10 - 13 % slower than six / seven waves of 64.)
@@ -385,7 +390,7 @@ unsigned blockThreads(int mode, const fsmc_model* m)
   return waveGroups(mode, m) ? (unsigned)(m->w2NW * kWave) : (unsigned)kWave;
 }
 
-// more than 512 states: the any-K kernel (fsmc_kernels_any.h)
+// more than 1024 states: the any-K kernel (fsmc_kernels_any.h)
 bool anyStates(const fsmc_model* m)
 {
   return m->K > kMaxStatesW2;

@@ -16,9 +16,9 @@
 //   consumers in array mode for launches that leave half the chip empty -- alpha from the window's start in one wave while
 //   beta comes from its end in another.
 // Wave-group kernel (decode_kernel_w2<KH, MODE, TRACK, SEQ, NW>), lane = pair and NW waves per group of KH states each:
-//   128 < K <= 256: four waves of 48 or 64 states; 256 < K <= 320: four waves of 80; 320 < K <= 512: six, seven or
-//   eight waves of 64.
-// Any-K kernel (decode_kernel_any<MODE, TRACK, SEQ>, fsmc_kernels_any.h): K > 512, a pair's K-vectors in the workspace
+//   128 < K <= 256: four waves of 48 or 64 states; 256 < K <= 320: four waves of 80; 320 < K <= 512: six, seven or eight
+//   waves of 64; 512 < K <= 1024: eight waves of 80, 96 or 128 (no landing zones).
+// Any-K kernel (decode_kernel_any<MODE, TRACK, SEQ>, fsmc_kernels_any.h): K > 1024, a pair's K-vectors in the workspace
 //   instead of registers -- correct, not fast; small enough to be instantiated where it is picked (fsmc_capi.hip).
 // (The runtime-K instantiation KT = 0 and the four-lanes-per-pair kernel of earlier builds are gone: every model of at
 //  most 256 states, in every mode, runs one of the two families above.)

@@ -1,7 +1,7 @@
-// fsmc_kernels_any.h -- the decode for models of ANY number of states (K > 512: beyond the lane-per-pair family of
+// fsmc_kernels_any.h -- the decode for models of ANY number of states (K > 1024: beyond the lane-per-pair family of
 // fsmc_kernels.h and the wave-group kernel of fsmc_kernels_w2.h).  The reference has no limit on K
-// (DecodingQuantities.cpp:72-78); the kernels that run at a roofline hold a pair's K-vectors in registers and stop at 512
-// states (eight waves of 64: the landing zones of a group's beta row fill the CU's LDS).  This one holds them in the wave's workspace instead: lane = pair as everywhere, a K-vector is a row of
+// (DecodingQuantities.cpp:72-78); the kernels that hold a pair's K-vectors in registers stop at 1024 states (eight waves
+// of 128, two of whose 256 registers' worth of vectors live in scratch memory already).  This one holds them in the wave's workspace instead: lane = pair as everywhere, a K-vector is a row of
 // [K/4][64 lanes] float4 in HBM / L2, and a step walks its states with real loops -- the reference's loops
 // (HMM.cpp:787-830 forward, 943-1016 backward, HmmUtils.cpp:102-151 scaling, HMM.cpp:669-692 combine), the same
 // operations in the same order, so the results are the oracle's bit for bit.  It moves several rows per step where the

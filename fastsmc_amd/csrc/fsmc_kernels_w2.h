@@ -1,5 +1,6 @@
-// fsmc_kernels_w2.h -- the decode kernel for wide models (128 < K <= 256; K = 256 is BASELINE.json config 4) with
-// lane = pair and SEVERAL WAVES per group.
+// fsmc_kernels_w2.h -- the decode kernel for wide models (128 < K <= 1024; K = 256 is BASELINE.json config 4) with
+// lane = pair and SEVERAL WAVES per group (what follows is written for four waves of up to 64 states, the members of up to
+// 256 states; the members beyond: w2Member, fsmc_capi.hip).
 //
 // A lane cannot hold the K-vectors of a 256-state model (2 x 256 registers is the whole file), and splitting a pair over
 // four lanes (the kernel this one replaced) leaves three quarters of a wave idle in every recurrence.  Here a workgroup of NW = 4 waves
@@ -314,7 +315,9 @@ __device__ __forceinline__ void beta_step_w2(const W2Ctx& cx, float (&b)[KH], fl
   //  measured in round 5: 3 % SLOWER at size and 8 % on 3000-site windows, interleaved on one box: the allocator's luck,
   //  not the instruction count, decides this kernel.  Not kept.)
   // (the members of more than 512 states -- eight waves of 80 / 96 / 128 -- serve every model that fills all but their last
-  //  TWO waves: 513 ... 560 states leave the seventh of eight 80-state waves with ghosts too)
+  //  TWO waves: 513 ... 560 states leave the seventh of eight 80-state waves with ghosts too.  The same for eight waves of
+  //  64, to serve 385 ... 448 states in place of the seven-wave member -- an odd group, slower than eight waves: 645
+  //  against 612 ms -- was measured: the second masked wave costs the eight-wave member exactly that, 612 -> 645 ms.)
   constexpr bool kMasked = KH == 48 ? (2 * H >= NW) : (KP > 512 ? H >= NW - 2 : H == NW - 1);
   auto ascending = [&](auto blockStates, const float blIn, const bool first) {
     constexpr int BS = decltype(blockStates)::value;

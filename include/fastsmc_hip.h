@@ -182,10 +182,11 @@ int fsmc_ctx_last_waves_per_window(const fsmc_ctx* ctx, int32_t* waves);
  * to L2.  The results do not depend on it. */
 int fsmc_ctx_last_segment_sums_in_lds(const fsmc_ctx* ctx, int32_t* in_lds);
 /* Which kernel the last launch ran: 16 ... 128 = the lane-per-pair kernel compiled for that many states (the exact
- * members 69, 50, 100, or the padded members 16, 32, 48, 64, 80, 96, 112, 128); the wave-group kernel (128 < K <= 512):
+ * members 69, 50, 100, or the padded members 16, 32, 48, 64, 80, 96, 112, 128); the wave-group kernel (128 < K <= 1024):
  * 1048 / 1064 / 1080 = four waves per group of 48 / 64 / 80 states (K <= 192 / 256 / 320), 6064 / 7064 / 8064 = six /
- * seven / eight waves of 64 states (K <= 384 / 448 / 512); 0 = the any-K kernel (512 < K <= 4096: a pair's K-vectors
- * live in the workspace instead of registers -- the same results, far from the roofline). */
+ * seven / eight waves of 64 states (K <= 384 / 448 / 512), 8080 / 8096 / 8128 = eight waves of 80 / 96 / 128 states
+ * (K <= 640 / 768 / 1024); 0 = the any-K kernel (1024 < K <= 4096: a pair's K-vectors live in the workspace instead of
+ * registers -- the same results, far from the roofline). */
 int fsmc_ctx_last_kernel(const fsmc_ctx* ctx, int32_t* member);
 
 /* ---- resident inputs ---- */

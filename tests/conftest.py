@@ -13,9 +13,9 @@ def pytest_configure(config):
 
 
 def wave_group_member(K):
-    """(waves per group, states per wave) of the wave-group kernel for a model of 128 < K <= 512 states, as
+    """(waves per group, states per wave) of the wave-group kernel for a model of 128 < K <= 1024 states, as
     fsmc_model_create picks it (csrc/fsmc_capi.hip, w2Member): four waves of 48 / 64 / 80 states, then six, seven, eight
-    waves of 64."""
+    waves of 64, beyond 512 states eight waves of 80 / 96 / 128."""
     forced = os.environ.get("FSMC_DIAG_W2_MEMBER")  # (A/B runs of another member: the library honours the same variable)
     if forced:
         nw, kh = (int(x) for x in forced.split("x"))

@@ -24,8 +24,10 @@ def _other_model(small_problem, K, time):
 
 # (K, time threshold): the 69-state exact member; the exact 50- and 100-state members; a padded member; the wave-group
 # kernel with two workgroups per CU (200 states, a threshold that reaches its second wave) and with one (300 states: four
-# waves of 80; 402: seven waves of 64, a threshold beyond 256 states; 460: eight waves); the any-K kernel (530)
-MODELS = [(69, 50), (50, 50), (100, 200), (105, 200), (200, 20000), (300, 200), (402, 30000), (460, 200), (530, 200)]
+# waves of 80; 402: seven waves of 64, a threshold beyond 256 states; 460: eight waves; 530:
+# eight waves of 80, no landing zones); the any-K kernel (1030)
+MODELS = [(69, 50), (50, 50), (100, 200), (105, 200), (200, 20000), (300, 200), (402, 30000), (460, 200), (530, 200),
+          (1030, 200)]
 
 
 @pytest.mark.parametrize("seed", list(range(10)))

@@ -522,6 +522,9 @@ def identify():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["c1", "k256", "hashing"]
     for w in what:
+        if w[0] == "k" and w[1:].isdigit():  # the 600 x 3000 list with a model of that many states
+            k256(int(w[1:]))
+            continue
         {"c1": c1, "c1_consumers": c1_consumers, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "k300": lambda: k256(300), "k320": lambda: k256(320), "k350": lambda: k256(350), "k402": lambda: k256(402),
          "k448": lambda: k256(448), "k500": lambda: k256(500), "k600": lambda: k256(600), "hashing": hashing,
          "short": short_windows, "run_c2": run_c2, "ingest_c3": ingest_c3, "c5_job": c5_job,

@@ -20,7 +20,7 @@ if [ $PART = pmc ] || [ $PART = all ]; then
 fi
 if [ $PART = round ] || [ $PART = all ]; then
   bash tools/measure_round.sh r05 > gpurun_out/r05_round.log 2>&1
-  python3 tools/measure_configs.py k320 k350 k402 k448 k500 k600 > gpurun_out/round_r05/wide_beyond_256.jsonl 2> gpurun_out/round_r05/wide_beyond_256.err
+  python3 tools/measure_configs.py k320 k350 k402 k448 k500 k520 k600 k640 k700 k768 k1000 k1100 > gpurun_out/round_r05/wide_beyond_256.jsonl 2> gpurun_out/round_r05/wide_beyond_256.err
   echo "round done"
 fi
 if [ $PART = extra ] || [ $PART = extra_nopmc ] || [ $PART = all ]; then
