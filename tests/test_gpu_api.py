@@ -233,12 +233,12 @@ def test_binary_output_round_trip(files, small_problem, tmp_path):
     assert n == len(text) and n > 100
 
 
-@pytest.mark.parametrize("K", [100, 300, 470, 530])
+@pytest.mark.parametrize("K", [100, 300, 470, 530, 1040])
 def test_fastsmc_run_wide_model_matches_oracle_text(small_problem, tmp_path, K):
     """The same end-to-end run with a 100-state model: routed to the 112-state member of the kernel family (12 ghost
     states) through the ordinary host path -- files, Data, HMM, FastSMC.run(), text output.  With 300 states: the
-    wave-group kernel at four waves of 80 states; with 470: eight waves of 64; with 530: beyond every register-resident
-    kernel, decoded by the any-K kernel (fsmc_kernels_any.h)."""
+    wave-group kernel at four waves of 80 states; with 470: eight waves of 64; with 530: eight waves of 80 without landing zones;
+    with 1040: beyond every register-resident kernel, decoded by the any-K kernel (fsmc_kernels_any.h)."""
     sp = dict(small_problem)
     sp["tables"] = synth.make_model_tables(K)
     root = str(tmp_path / "syn100")
