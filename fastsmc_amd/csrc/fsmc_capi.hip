@@ -668,7 +668,7 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
     // checkpoint row and a pipeline restart each and let the resident chunks (below) fill the memory that is left to
     // the last row: C2 at 2048 / 1024 / 512 sites a chunk runs 1886 / 1881 / 1870 ms.
     C = ctx->chunkSites ? (size_t)ctx->chunkSites : defaultChunk;
-    // (the wave-group kernel has no resident chunks and pays more per restart: 2048)
+    // (the wave-group kernel pays more per restart: 2048)
     C = std::min((C + 15) / 16 * 16, (L + 15) / 16 * 16);
     auto fits = [&](size_t c) { return chunkRows(c) + (L + c - 1) / c + sideRows + 1 <= rowsAvail; };
     if (!ctx->chunkSites) {
@@ -683,10 +683,10 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   }
   // Resident chunks (fsmc_kernels.h): a chunked window rebuilds every chunk's rows from a checkpoint -- one of its 3.5
   // sweeps -- except for the chunks whose rows pass B can leave in the workspace.  Whatever the limit leaves after the
-  // one chunk buffer, the checkpoints and the parking rows goes to such chunks (array-mode IBD decode of the
-  // lane-per-pair family, one group per wave: the paired kernel is not built with them).
+  // one chunk buffer, the checkpoints and the parking rows goes to such chunks (array-mode IBD decode and sums of the
+  // lane-per-pair family, one group per wave -- the paired kernel is not built with them -- and of the wave-group kernel).
   size_t resident = 0;
-  if (maxChunks > 1 && (mode == kModeIbd || mode == kModeSums) && !m->sequence && !w2 && !paired && !anyStates(m) &&
+  if (maxChunks > 1 && (mode == kModeIbd || mode == kModeSums) && !m->sequence && !paired && !anyStates(m) &&
       ctx->residentChunks != 0) {
     const size_t rowsBudget = rowsSoft;
     // (exactly the rows of plan.wsSlot below: a plan must qualify again for the buffer it was given -- with a row of

@@ -822,6 +822,12 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
   float4* const saveA = ckpt + (size_t)(p.maxChunks + 2) * vecF4;
   float4* const saveS = saveA + vecF4;
   float4* const spsMem = saveS + lane; // this lane's column of the per-state posterior sums (all states)
+  // Resident chunks (array mode; the host plans p.residentChunks extra chunk buffers per workgroup, fsmc_kernels.h, same
+  // place): pass B leaves the rows of the window's FIRST chunks -- the last ones it walks through, the first ones the
+  // alpha sweep needs -- in the workspace, one row per site from the window's first site on, and pass A sweeps those
+  // chunks without rebuilding them.  The same rows the rebuild would produce: the same steps from the same vectors.
+  float4* const resBase = saveS + vecF4;
+  const int nResident = SEQ ? 0 : p.residentChunks;
   const unsigned laneOff = (unsigned)lane * (unsigned)sizeof(float4);
   const int C = p.chunk;
   const cfloat_p rowSets = (cfloat_p)p.rowSets;
@@ -1083,20 +1089,41 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
             storeHalf(chunkbuf, b); // beta of the window's first site
           }
         } else {
+          // the sites whose rows stay: [from, resEnd); the lowest vector pass B has to reach: beta of the window's first
+          // site if there are such rows, otherwise the first checkpoint (the first chunk is rebuilt from it)
+          const int resEnd = (from + nResident * C < aEnd) ? from + nResident * C : aEnd;
+          const int lowest = nResident > 0 ? from : from + C;
           bool stored = afterBeta(to - 1);
-          if (to - 2 >= from) {
+          if (to - 2 >= lowest) {
             stored = false; // (the request is behind the stores: wait for everything once)
           }
-          for (int pos = to - 2; pos >= from; --pos) {
+          int pos = to - 2;
+          // above the resident rows: checkpoints only
+          for (; pos >= lowest && pos + 1 >= resEnd; --pos) {
             const int q = pos + 1;
             waitEmisRows(stored);
             __builtin_amdgcn_wave_barrier();
             FSMC_END(cycW, 29);
-            if (pos - 1 >= from) {
+            if (pos - 1 >= lowest) {
               stageEmis(q - 1);
             }
             betaStepInto(b, w, q, std::false_type{}, nullptr);
             stored = afterBeta(pos);
+          }
+          // the resident rows: the row of site q rides out during the step that starts from it (as in a single-chunk
+          // window), the window's first behind the loop; no checkpoints down here -- these chunks are not rebuilt
+          if (nResident > 0) {
+            for (; pos >= from; --pos) {
+              const int q = pos + 1;
+              waitEmisRows(stored);
+              __builtin_amdgcn_wave_barrier();
+              if (pos - 1 >= from) {
+                stageEmis(q - 1);
+              }
+              betaStepInto(b, w, q, std::true_type{}, resBase + (size_t)(q - from) * vecF4);
+              stored = true;
+            }
+            storeHalf(resBase, b); // beta of the window's first site
           }
         }
       }
@@ -1138,7 +1165,10 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
       }
       const int lo = from + j * C;
       const int hi = (lo + C < aEnd) ? lo + C : aEnd;
-      if (!single) {
+      // the rows of this chunk: kept by pass B (a resident chunk), or rebuilt below into the chunk buffer
+      const bool resident = !single && j < nResident;
+      float4* const cbuf = resident ? resBase + (size_t)(lo - from) * vecF4 : chunkbuf;
+      if (!single && !resident) {
         if (j > 0) {
           storeHalf(saveA, a);
         }
@@ -1202,7 +1232,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
       // this wave's own stores of the chunk's betas must have landed before its DMA reads them back
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       waitVm0();
-      fetchBeta(chunkbuf);
+      fetchBeta(cbuf);
       // sites whose emission rows the sweep of this chunk needs: sequence mode also takes the half-step out of the
       // chunk's last site, with the homozygous row of the site behind it
       const int stageEnd = SEQ ? (hi + 1 < to ? hi + 1 : to) : hi;
@@ -1235,7 +1265,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
           // landing zone.  (The chunk's first row was requested in front of the loop: its step requests it once more,
           // the same bytes.  The sums consumer transposes its tile through the zone and requests the next row itself.)
           if constexpr (MODE != kModeSums && LAND) {
-            const RowIO in = {uniformPtr(chunkbuf + (size_t)(pos - lo) * vecF4 + halfF4), laneOff, &betaLds[h][0]};
+            const RowIO in = {uniformPtr(cbuf + (size_t)(pos - lo) * vecF4 + halfF4), laneOff, &betaLds[h][0]};
             FSMC_W2_ROLE(h, (alpha_step_w2<NW, KH, H, true, true>(cx, a, w, rsp, tCR, e, cycW, in)));
           } else {
             FSMC_W2_ROLE(h, (alpha_step_w2<NW, KH, H>(cx, a, w, rsp, tCR, e, cycW, noRowIO())));
@@ -1261,7 +1291,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
         //  products as operands and clobbers memory; a scheduling barrier alone does not bind instruction selection)
         if constexpr (!LAND) {
           // no landing zone: this wave's part of the row out of the workspace (w is free between the step and the combine)
-          loadHalf(chunkbuf + (size_t)(pos - lo) * vecF4, w);
+          loadHalf(cbuf + (size_t)(pos - lo) * vecF4, w);
 #pragma unroll
           for (int k = 0; k < KH; k += 2) {
             const f32x2 av = {a[k], a[k + 1]}, bv = {w[k], w[k + 1]};
@@ -1413,7 +1443,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
           waitLgkm0();
           __builtin_amdgcn_wave_barrier();
           if (pos + 1 < hi) {
-            fetchBeta(chunkbuf + (size_t)(pos + 1 - lo) * vecF4);
+            fetchBeta(cbuf + (size_t)(pos + 1 - lo) * vecF4);
           }
         }
 

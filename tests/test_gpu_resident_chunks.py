@@ -167,3 +167,68 @@ def test_workspace_growth_is_amortised(small_problem, monkeypatch):
     assert resident[:4] == [0, 0, 0, 0]                                  # ... not before the credit covers 2 x the buffer
     steps = sum(1 for a, b in zip(resident, resident[1:]) if b != a)
     assert steps <= 4, resident                                          # ... and in a few steps, not one per launch
+
+
+@pytest.mark.parametrize("K", [200, 300, 530])
+def test_wave_group_kernel_records_and_sums_do_not_depend_on_resident_chunks(K):
+    """The wave-group kernel (four waves of 64 / 80 states; eight waves of 80 without landing zones) keeps resident chunks
+    too: records with ages and the sums over pairs of chunked windows are the same bytes with 0, 1, 2 and every chunk
+    resident, and the records are the oracle's."""
+    from fastsmc_amd import synth
+    from conftest import expected_member
+
+    tables = synth.make_model_tables(K)
+    haps = synth.make_haps(64, 333, seed=K, cm_per_mb=25.0, switch_per_cm=0.6)
+    bits, derived, flipped = synth.fold_and_pack(haps.alleles)
+    folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
+    gen = (haps.cm / 100.0).astype(np.float32)
+    pm = O.prepare_model(tables, gen, haps.bp, derived, 64, time=200)
+    wins = [(0, 64, 0, 333, 0, 333), (64, 40, 3, 330, 3, 330), (104, 64, 10, 331, 37, 300), (168, 9, 100, 101, 100, 101),
+            (177, 33, 200, 202, 200, 202), (210, 64, 5, 222, 6, 221), (274, 20, 0, 49, 0, 49), (294, 64, 290, 333, 301, 333),
+            (358, 64, 0, 333, 100, 150)]
+    n = wins[-1][0] + wins[-1][1]
+    pairs = O.enumerate_all_pairs(32)[100:100 + n]
+    groups = np.zeros(len(wins), capi.GROUP_DTYPE)
+    for g, w in zip(groups, wins):
+        g["first_pair"], g["n_pairs"], g["from"], g["to"], g["scan_from"], g["scan_to"] = w
+    pr = np.array(pairs, dtype=np.uint32).view(capi.PAIR_DTYPE).reshape(-1)
+    flags = capi.FSMC_WANT_MEAN | capi.FSMC_WANT_MAP
+    rec, sums = {}, {}
+    for resident in (0, 1, 2, -1):
+        ctx = capi.Context(0)
+        model = ctx.create_model(pm)
+        ctx.upload_haps(bits, pm.S)
+        ctx.set_chunk_sites(48)
+        ctx.set_workspace_limit(1 << 30)
+        ctx.set_resident_chunks(resident)
+        rec[resident] = ctx.decode_ibd(model, pr, groups, flags)
+        assert ctx.last_kernel() == expected_member(K)
+        chunks = ctx.info()["max_chunks"]
+        assert chunks > 4
+        assert ctx.last_resident_chunks() == (resident if resident >= 0 else chunks)
+        ctx.upload_worklist(pr[:64], capi.whole_sequence_groups(64, pm.S))
+        sums[resident] = ctx.decode_sums(model)[0]
+        assert ctx.last_resident_chunks() == (resident if resident >= 0 else ctx.info()["max_chunks"])
+        ctx.close()
+    for r in (1, 2, -1):
+        assert rec[r].tobytes() == rec[0].tobytes(), f"records, resident = {r}"
+        assert sums[r].tobytes() == sums[0].tobytes(), f"sums, resident = {r}"
+    want = []
+    for first, cnt, frm, to, sfrm, sto in wins:
+        sub = pairs[first:first + cnt]
+        ob = np.stack([(folded[a] ^ folded[b])[frm:to] for a, b in sub])
+        hb = np.stack([(folded[a] & folded[b])[frm:to] for a, b in sub])
+        post, _ = O.decode_batch(pm, ob, hb, frm, to)
+        full = np.zeros((pm.S, pm.K, cnt), np.float32)
+        full[frm:to] = post[frm:to]
+        for v in range(cnt):
+            want.append(O.ibd_scan_pair(pm, full, v, sfrm, sto, pair_ordinal=first + v, want_mean=True, want_map=True))
+    want = np.concatenate(want)
+    assert want.size > 10
+    _assert_records_equal(rec[-1], want)
+    ob = np.stack([folded[a] ^ folded[b] for a, b in pairs[:64]])
+    hb = np.stack([folded[a] & folded[b] for a, b in pairs[:64]])
+    wpost, _ = O.decode_batch(pm, ob, hb, 0, pm.S)
+    wsum = np.zeros((pm.S, pm.K), np.float32)
+    O.augment_sum_over_pairs(pm, wpost, 64, ob, hb, wsum)
+    np.testing.assert_array_equal(sums[-1], wsum)
