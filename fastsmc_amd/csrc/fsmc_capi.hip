@@ -684,9 +684,11 @@ int planLaunch(fsmc_ctx* ctx, const fsmc_model* m, int mode, KernelFn fn, Launch
   // Resident chunks (fsmc_kernels.h): a chunked window rebuilds every chunk's rows from a checkpoint -- one of its 3.5
   // sweeps -- except for the chunks whose rows pass B can leave in the workspace.  Whatever the limit leaves after the
   // one chunk buffer, the checkpoints and the parking rows goes to such chunks (array-mode IBD decode and sums of the
-  // lane-per-pair family, one group per wave -- the paired kernel is not built with them -- and of the wave-group kernel).
+  // lane-per-pair family, one group per wave -- the paired kernel is not built with them -- and of the wave-group kernel's
+  // four-wave members).
   size_t resident = 0;
   if (maxChunks > 1 && (mode == kModeIbd || mode == kModeSums) && !m->sequence && !paired && !anyStates(m) &&
+      (!w2 || w2ResidentBuilt(m->w2NW, false)) &&
       ctx->residentChunks != 0) {
     const size_t rowsBudget = rowsSoft;
     // (exactly the rows of plan.wsSlot below: a plan must qualify again for the buffer it was given -- with a row of

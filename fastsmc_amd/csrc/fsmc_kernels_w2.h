@@ -764,6 +764,8 @@ __device__ __forceinline__ void alpha_step_w2(const W2Ctx& cx, float (&a)[KH], f
 // of 64 states: 321 ... 512 states; landing zones of 96 ... 128 KiB; more than four waves a CU leave a wave 256
 // registers, the four-wave 64-state member's budget).
 constexpr int w2WorkgroupsPerCU(int KH, int NW = kW2NW) { return NW == kW2NW && KH <= 64 ? FSMC_W2_WG_PER_CU : 1; }
+// members built with resident chunks (the kernel, same name)
+constexpr bool w2ResidentBuilt(int NW, bool SEQ) { return NW == kW2NW && !SEQ; }
 template <int KH, int MODE, bool TRACK, bool SEQ = false, int NW = kW2NW>
 __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_kernel_w2(const KParams p)
 {
@@ -826,8 +828,14 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
   // place): pass B leaves the rows of the window's FIRST chunks -- the last ones it walks through, the first ones the
   // alpha sweep needs -- in the workspace, one row per site from the window's first site on, and pass A sweeps those
   // chunks without rebuilding them.  The same rows the rebuild would produce: the same steps from the same vectors.
+  // Built for the four-wave members in array mode (w2ResidentBuilt: what the host's planner asks): in the members of
+  // six to eight waves the same lines -- two more copies of every wave's step function in the kernel -- moved the
+  // register allocation of code that has nothing to do with them, and their SINGLE-chunk windows ran 3 - 14 % slower
+  // (600 x 3000 list, K = 350 467 -> 482 ms, K = 500 612 -> 700 ms, K = 600 1150 -> 1238 ms); those members are compiled
+  // from the lines they had.
   float4* const resBase = saveS + vecF4;
-  const int nResident = SEQ ? 0 : p.residentChunks;
+  constexpr bool kResidentBuilt = w2ResidentBuilt(NW, SEQ);
+  const int nResident = kResidentBuilt ? p.residentChunks : 0;
   const unsigned laneOff = (unsigned)lane * (unsigned)sizeof(float4);
   const int C = p.chunk;
   const cfloat_p rowSets = (cfloat_p)p.rowSets;
@@ -1088,7 +1096,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
           if (from < aEnd) {
             storeHalf(chunkbuf, b); // beta of the window's first site
           }
-        } else {
+        } else if constexpr (kResidentBuilt) {
           // the sites whose rows stay: [from, resEnd); the lowest vector pass B has to reach: beta of the window's first
           // site if there are such rows, otherwise the first checkpoint (the first chunk is rebuilt from it)
           const int resEnd = (from + nResident * C < aEnd) ? from + nResident * C : aEnd;
@@ -1124,6 +1132,22 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
               stored = true;
             }
             storeHalf(resBase, b); // beta of the window's first site
+          }
+        } else {
+          bool stored = afterBeta(to - 1);
+          if (to - 2 >= from) {
+            stored = false; // (the request is behind the stores: wait for everything once)
+          }
+          for (int pos = to - 2; pos >= from; --pos) {
+            const int q = pos + 1;
+            waitEmisRows(stored);
+            __builtin_amdgcn_wave_barrier();
+            FSMC_END(cycW, 29);
+            if (pos - 1 >= from) {
+              stageEmis(q - 1);
+            }
+            betaStepInto(b, w, q, std::false_type{}, nullptr);
+            stored = afterBeta(pos);
           }
         }
       }
@@ -1166,7 +1190,7 @@ __global__ __launch_bounds__(NW * kWave, w2WorkgroupsPerCU(KH, NW)) void decode_
       const int lo = from + j * C;
       const int hi = (lo + C < aEnd) ? lo + C : aEnd;
       // the rows of this chunk: kept by pass B (a resident chunk), or rebuilt below into the chunk buffer
-      const bool resident = !single && j < nResident;
+      const bool resident = kResidentBuilt && !single && j < nResident;
       float4* const cbuf = resident ? resBase + (size_t)(lo - from) * vecF4 : chunkbuf;
       if (!single && !resident) {
         if (j > 0) {

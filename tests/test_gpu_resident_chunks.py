@@ -171,9 +171,10 @@ def test_workspace_growth_is_amortised(small_problem, monkeypatch):
 
 @pytest.mark.parametrize("K", [200, 300, 530])
 def test_wave_group_kernel_records_and_sums_do_not_depend_on_resident_chunks(K):
-    """The wave-group kernel (four waves of 64 / 80 states; eight waves of 80 without landing zones) keeps resident chunks
-    too: records with ages and the sums over pairs of chunked windows are the same bytes with 0, 1, 2 and every chunk
-    resident, and the records are the oracle's."""
+    """The wave-group kernel's four-wave members (here 64 and 80 states a wave) keep resident chunks too: records with ages
+    and the sums over pairs of chunked windows are the same bytes with 0, 1, 2 and every chunk resident, and the records
+    are the oracle's.  The members of more waves (530 states: eight waves of 80) are not built with them: the setting is
+    accepted and the plan has none."""
     from fastsmc_amd import synth
     from conftest import expected_member
 
@@ -205,10 +206,11 @@ def test_wave_group_kernel_records_and_sums_do_not_depend_on_resident_chunks(K):
         assert ctx.last_kernel() == expected_member(K)
         chunks = ctx.info()["max_chunks"]
         assert chunks > 4
-        assert ctx.last_resident_chunks() == (resident if resident >= 0 else chunks)
+        built = expected_member(K) < 2000  # (1000 + states per wave: four waves a group)
+        assert ctx.last_resident_chunks() == ((resident if resident >= 0 else chunks) if built else 0)
         ctx.upload_worklist(pr[:64], capi.whole_sequence_groups(64, pm.S))
         sums[resident] = ctx.decode_sums(model)[0]
-        assert ctx.last_resident_chunks() == (resident if resident >= 0 else ctx.info()["max_chunks"])
+        assert ctx.last_resident_chunks() == ((resident if resident >= 0 else ctx.info()["max_chunks"]) if built else 0)
         ctx.close()
     for r in (1, 2, -1):
         assert rec[r].tobytes() == rec[0].tobytes(), f"records, resident = {r}"
