@@ -48,7 +48,7 @@ def _invariants(rec, n_pairs, S):
 
 
 def _whole_sequence_case(n_hap, S, K, n_pairs, n_sample, want_member, time=50, seed=1234, oracle_batch=32,
-                         oracle_threads=None):
+                         oracle_threads=None, chunk=2048, group_mb=None, want_resident=None):
     """All-pairs-style list over whole-sequence windows: decode twice, check invariants, sample against the oracle (its
     -mavx2 build, which tests/test_oracle_builds.py holds bit-identical to the checker build, one batch per host
     thread; `oracle_batch` bounds a thread's two S x K x batch buffers -- per-pair results do not depend on it)."""
@@ -67,17 +67,20 @@ def _whole_sequence_case(n_hap, S, K, n_pairs, n_sample, want_member, time=50, s
         ctx.upload_worklist(pairs.view(capi.PAIR_DTYPE).reshape(-1), capi.whole_sequence_groups(n_pairs, pm.S, batch=64))
         # the chunk length the full-size list gets (2048 resident waves share the workspace); with the few waves
         # of this sample every beta row would fit and the rebuild pass would never run
-        ctx.set_chunk_sites(2048)
-        ctx.set_workspace_limit((n_pairs // 64) * (4 if K > 80 else 1) * (40 << 20))  # 40 MB a wave, as at full size
+        ctx.set_chunk_sites(chunk)
+        # 40 MB a wave, as at full size (`group_mb`: a case that wants room for resident chunks, or has wider rows)
+        ctx.set_workspace_limit((n_pairs // 64) * ((group_mb << 20) if group_mb else (4 if K > 80 else 1) * (40 << 20)))
         ctx.decode_ibd_launch(model)
         rec = ctx.decode_ibd_fetch()
         ctx.decode_ibd_launch(model)
         again = ctx.decode_ibd_fetch()
-        info, member = ctx.info(), ctx.last_kernel()
+        info, member, resident = ctx.info(), ctx.last_kernel(), ctx.last_resident_chunks()
     finally:
         ctx.close()
     assert member == want_member
     assert info["max_chunks"] > 1, "the configuration must run through the checkpointed (chunked) layout"
+    if want_resident is not None:
+        assert resident == want_resident
     assert rec.tobytes() == again.tobytes()
     assert rec.size > 20
     _invariants(rec, n_pairs, S)
@@ -112,6 +115,19 @@ def test_c4_256_states_200k_sites_chunked_wide_model_kernel():
     # 128 of the 2048 pairs against the oracle (8 pairs a batch on 8 threads: 26 GB of oracle buffers, ~15 s)
     _whole_sequence_case(n_hap=128, S=200000, K=256, n_pairs=2048, n_sample=128, want_member=1064, time=200,
                          oracle_batch=8, oracle_threads=8)
+
+
+def test_256_states_60k_sites_with_resident_chunks():
+    # config 4's kernel with room for two resident chunks a group (what the full-size run gets from 80 % of
+    # the card): 64 of the 1024 pairs against the oracle
+    _whole_sequence_case(n_hap=128, S=60000, K=256, n_pairs=1024, n_sample=64, want_member=1064, time=200,
+                         oracle_batch=8, oracle_threads=8, group_mb=400, want_resident=2)
+
+
+def test_600_states_30k_sites_chunked_eight_wave_member_without_landing_zones():
+    # a model beyond 512 states on long windows (rows of 160 KiB; chunks of 1024 sites): 64 of the 512 pairs
+    _whole_sequence_case(n_hap=64, S=30000, K=600, n_pairs=512, n_sample=64, want_member=8080, time=200,
+                         oracle_batch=8, oracle_threads=8, chunk=1024, group_mb=320, want_resident=0)
 
 
 def test_c1_reference_example_data_job_7_of_9(tmp_path):
