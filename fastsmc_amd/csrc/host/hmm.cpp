@@ -16,6 +16,7 @@
 #include <map>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 #include <sys/stat.h>
 
@@ -793,11 +794,31 @@ void HMM::flush()
     mTimeDecode += since(t0);
     hostMark("flush: records fetched");
     t0 = Clock::now();
-    for (size_t i = 0; i < n; ++i) {
-      if (mKeepRecords) {
-        mKeptOrdinals.push_back(mPairsFlushed + recs[i].pair);
+    if (mIbdFile && !mParams.BIN_OUT && n >= 512) {
+      // a flush's text in one piece (formatted by several threads), then what writeIbd does beside the text
+      std::vector<uint32_t> pairOf(n);
+      for (size_t i = 0; i < n; ++i) {
+        pairOf[i] = recs[i].pair;
       }
-      writeIbd(mPairs[recs[i].pair], recs[i]);
+      const std::string text = formatIbdRecords(mPairs.data(), recs.data(), n, pairOf.data());
+      for (size_t off = 0; off < text.size(); off += (size_t)1 << 30) {
+        gzwrite(mIbdFile, text.data() + off, static_cast<unsigned>(std::min<size_t>(text.size() - off, (size_t)1 << 30)));
+      }
+      mSegmentsDetected += n;
+      if (mKeepRecords) {
+        for (size_t i = 0; i < n; ++i) {
+          mKeptOrdinals.push_back(mPairsFlushed + recs[i].pair);
+          mKeptRecords.push_back(recs[i]);
+          mKeptPairs.push_back(mPairs[recs[i].pair]);
+        }
+      }
+    } else {
+      for (size_t i = 0; i < n; ++i) {
+        if (mKeepRecords) {
+          mKeptOrdinals.push_back(mPairsFlushed + recs[i].pair);
+        }
+        writeIbd(mPairs[recs[i].pair], recs[i]);
+      }
     }
     mTimeWrite += since(t0);
   }
@@ -997,8 +1018,15 @@ void HMM::writeIbdRecordsTo(const std::string& fileName, const std::vector<fsmc_
   if (mParams.BIN_OUT) {
     writeBinaryHeader(file);
   }
-  for (size_t i = 0; i < records.size(); ++i) {
-    emitIbd(file, pairs[i], records[i]);
+  if (!mParams.BIN_OUT) {
+    const std::string text = formatIbdRecords(pairs.data(), records.data(), records.size());
+    for (size_t off = 0; off < text.size(); off += (size_t)1 << 30) {
+      gzwrite(file, text.data() + off, static_cast<unsigned>(std::min<size_t>(text.size() - off, (size_t)1 << 30)));
+    }
+  } else {
+    for (size_t i = 0; i < records.size(); ++i) {
+      emitIbd(file, pairs[i], records[i]);
+    }
   }
   gzclose(file);
 }
@@ -1197,10 +1225,44 @@ void HMM::closeIBDFile()
 
 std::string HMM::formatIbdRecord(const fsmc_pair& pr, const fsmc_ibd_record& r) const
 {
-  const auto [iInd, iHap] = hapToDipId(pr.hap_a);
-  const auto [jInd, jHap] = hapToDipId(pr.hap_b);
   std::stringstream record;
   record << std::setprecision(std::numeric_limits<float>::digits10 + 1);
+  putIbdRecord(record, pr, r);
+  return record.str();
+}
+
+std::string HMM::formatIbdRecords(const fsmc_pair* pairs, const fsmc_ibd_record* records, size_t n,
+                                  const uint32_t* pairOf) const
+{
+  auto part = [&](size_t lo, size_t hi) {
+    std::ostringstream text;
+    text << std::setprecision(std::numeric_limits<float>::digits10 + 1);
+    for (size_t i = lo; i < hi; ++i) {
+      putIbdRecord(text, pairs[pairOf ? pairOf[i] : i], records[i]);
+    }
+    return text.str();
+  };
+  const size_t perThread = 256;
+  const size_t nThreads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16, n / perThread});
+  if (nThreads < 2) {
+    return part(0, n);
+  }
+  std::vector<std::future<std::string>> parts;
+  for (size_t t = 0; t < nThreads; ++t) {
+    parts.push_back(std::async(std::launch::async, part, n * t / nThreads, n * (t + 1) / nThreads));
+  }
+  std::string out;
+  for (auto& f : parts) {
+    out += f.get();
+  }
+  return out;
+}
+
+// (the stream carries the precision: std::numeric_limits<float>::digits10 + 1)
+void HMM::putIbdRecord(std::ostream& record, const fsmc_pair& pr, const fsmc_ibd_record& r) const
+{
+  const auto [iInd, iHap] = hapToDipId(pr.hap_a);
+  const auto [jInd, jHap] = hapToDipId(pr.hap_b);
   record << mData.FamIDList[iInd] << '\t' << mData.IIDList[iInd] << '\t' << static_cast<int>(iHap) << '\t'
          << mData.FamIDList[jInd] << '\t' << mData.IIDList[jInd] << '\t' << static_cast<int>(jHap) << '\t'
          << mData.chrNumber;
@@ -1218,7 +1280,6 @@ std::string HMM::formatIbdRecord(const fsmc_pair& pr, const fsmc_ibd_record& r) 
     record << '\t' << r.map;
   }
   record << '\n';
-  return record.str();
 }
 
 void HMM::writeIbd(const fsmc_pair& pr, const fsmc_ibd_record& r)

@@ -469,13 +469,9 @@ PYBIND11_MODULE(_pyasmc, m)
            "the kept IBD records as numpy columns; `pair` = ordinal of the record's pair among all pairs decoded so far")
       .def("getIbdLines",
            [](const HMM& h) {
-             std::string s;
              const auto& r = h.getIbdRecords();
              const auto& p = h.getIbdRecordPairs();
-             for (size_t i = 0; i < r.size(); ++i) {
-               s += h.formatIbdRecord(p[i], r[i]);
-             }
-             return s;
+             return h.formatIbdRecords(p.data(), r.data(), r.size());
            })
       .def("preparedModel", [](const HMM& h) {
         const PreparedModel& pm = h.getPreparedModel();
