@@ -222,6 +222,7 @@ private:
 
   // outputs
   gzFile mIbdFile = nullptr;
+  int mIbdFd = -1; // its descriptor (whole gzip members of a flush's text are written through it: putIbdText)
   unsigned long long mSegmentsDetected = 0;
   DecodingReturnValues mReturn;
   DecodePairsReturnStruct mPairsReturn;

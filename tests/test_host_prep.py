@@ -299,3 +299,36 @@ def test_bench_unpacks_the_folded_alleles_it_gives_the_cpu_baseline():
         folded = np.where(flipped[None, :], 1 - haps.alleles, haps.alleles).astype(np.uint8)
         rows = np.array([0, 3, 17, 63])
         np.testing.assert_array_equal(bench.folded_rows_from_bits(bits, rows, n_sites), folded[rows])
+
+
+def test_ibd_text_of_many_records_is_the_text_of_few(small_problem, tmp_path):
+    """A flush of many records is formatted by several threads and compressed into gzip members of their own
+    (host/hmm.cpp: formatIbdRecords, putIbdText); the text a reader sees must be what the small-flush path -- one stream,
+    gzwrite -- writes for the same records.  No device: writeIbdRecordArrays only formats and writes."""
+    import gzip
+
+    sp = small_problem
+    data = api.Data.from_arrays(sp["haps"].alleles, sp["haps"].bp, sp["haps"].cm, True, True)
+    hmm = api.HMM(data, api.decoding_quantities_from_tables(sp["tables"]), _params())
+    rng = np.random.default_rng(5)
+    n, S, H = 30000, sp["haps"].alleles.shape[1], sp["haps"].alleles.shape[0]
+    start = rng.integers(0, S - 1, n)
+    cols = dict(hap_a=rng.integers(0, H, n).astype(np.uint32), hap_b=rng.integers(0, H, n).astype(np.uint32),
+                start=start.astype(np.int32), end=np.minimum(start + rng.integers(0, 200, n), S - 1).astype(np.int32),
+                prob=rng.random(n).astype(np.float32) * 50, post_mean=rng.random(n).astype(np.float32) * 3000,
+                map=rng.integers(0, 69, n).astype(np.float32))
+    big = str(tmp_path / "big.ibd.gz")
+    hmm.writeIbdRecordArrays(big, **cols)
+    text = gzip.open(big, "rt").read()
+    assert text.count("\n") == n
+    few = []
+    for lo in range(0, n, 3000):  # (slices of 300 records: below the threshold of either mechanism)
+        name = str(tmp_path / "few.ibd.gz")
+        hmm.writeIbdRecordArrays(name, **{k: v[lo:lo + 300] for k, v in cols.items()})
+        few.append((lo, gzip.open(name, "rt").read()))
+    lines = text.splitlines(keepends=True)
+    for lo, t in few:
+        assert "".join(lines[lo:lo + 300]) == t
+    # every reader of gzip files sees one stream: zlib's own too
+    import subprocess
+    assert subprocess.run(["zcat", big], capture_output=True, check=True).stdout.decode() == text
