@@ -237,6 +237,47 @@ def hashing():
                       "all_pairs": n_hap * (n_hap - 1) // 2 + 0}))
 
 
+
+def run_c1_asmc(n_hap=300, n_sites=6760):
+    """The reference's ONE published timing -- `ASMC_regression [HMM_regression]` (test_regression.cpp:23-68,
+    time_regression.py:1-3: read the n300 array example, build the HMM, decodeAll with doPosteriorSums over all 44 850
+    pairs; median 51.97 s) -- through the PRODUCT path on files of that shape: Data + HMM construction, then
+    ASMC.decodeAllInJob() and the [sites][states] sums back in numpy."""
+    from oracle import oracle as O
+
+    tables = synth.make_model_tables(69)
+    haps = synth.make_haps(n_hap, n_sites, seed=1234)
+    with tempfile.TemporaryDirectory() as d:
+        root = os.path.join(d, "syn")
+        synth.write_haps_files(root, haps, fastsmc_map=False)
+        # (ASMC mode reads the plink map and computes gen = stof(cM) / 100.f in float, Data.cpp:186: the keys of both)
+        gen = (haps.cm / 100.0).astype(np.float32)
+        gen32 = np.array([np.float32(np.float32(c) / np.float32(100.0)) for c in haps.cm], np.float32)
+        used = np.unique(np.concatenate([[0.0], O.step_rows(tables.keys, gen)[1][1:], O.step_rows(tables.keys, gen32)[1][1:]]))
+        t = copy.copy(tables)
+        sel = np.nonzero(np.isin(t.keys, used.astype(np.float32)))[0]
+        t.keys, t.D, t.B, t.U, t.RR = t.keys[sel], t.D[sel], t.B[sel], t.U[sel], t.RR[sel]
+        synth.write_decoding_quantities(root + ".decodingQuantities.gz", t)
+        # the constructor call of test_regression.cpp:27-41 (doPosteriorSums = true)
+        p = api.DecodingParams(root, root + ".decodingQuantities.gz", "", 1, 1, "array", False, True, False, False, 0.0,
+                               False, True)
+        p.useKnownSeed = True
+        for rep in range(2):  # (the first job of a process pays the HIP runtime's start-up)
+            t0 = time.perf_counter()
+            asmc = api.ASMC(p)
+            t_init = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ret = asmc.decodeAllInJob()
+            sums = np.asarray(ret.sumOverPairs)
+            t_run = time.perf_counter() - t0
+            n_pairs = n_hap * (n_hap - 1) // 2
+            print(json.dumps({"config": "run_c1_asmc_published_job", "job_of_this_process": rep + 1, "haplotypes": n_hap,
+                              "sites": n_sites, "K": 69, "pairs": n_pairs, "construct_s": t_init, "decode_all_s": t_run,
+                              "job_s": t_init + t_run, "pairs_per_s_job": n_pairs / (t_init + t_run),
+                              "reference_published_s": 51.97, "speedup_over_published": 51.97 / (t_init + t_run),
+                              "sums_shape": list(sums.shape), "sums_checksum": float(np.float64(sums.sum()))}), flush=True)
+            del asmc
+
 def run_c2(n_hap=1000, n_sites=50000):
     """The PRODUCT path at the bench's size: FastSMC(params).run() end to end on C2 files -- read .hap.gz / .samples /
     .map / .decodingQuantities.gz, enumerate all pairs in batches of 32 (the reference default), decode, format and
@@ -527,5 +568,5 @@ if __name__ == "__main__":
             continue
         {"c1": c1, "c1_consumers": c1_consumers, "k256": k256, "k100": lambda: k256(100), "k128": lambda: k256(128), "k192": lambda: k256(192), "k300": lambda: k256(300), "k320": lambda: k256(320), "k350": lambda: k256(350), "k402": lambda: k256(402),
          "k448": lambda: k256(448), "k500": lambda: k256(500), "k600": lambda: k256(600), "hashing": hashing,
-         "short": short_windows, "run_c2": run_c2, "ingest_c3": ingest_c3, "c5_job": c5_job,
+         "short": short_windows, "run_c2": run_c2, "run_c1_asmc": run_c1_asmc, "ingest_c3": ingest_c3, "c5_job": c5_job,
          "ingest_small": lambda: ingest_c3(2000, 20000), "identify": identify, "seq": seq, "seq100": lambda: seq(100)}[w]()

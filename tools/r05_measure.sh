@@ -30,6 +30,7 @@ if [ $PART = extra ] || [ $PART = extra_nopmc ] || [ $PART = all ]; then
   python3 tools/measure_configs.py c1_consumers > gpurun_out/round_r05/c1_consumers.jsonl 2> gpurun_out/round_r05/c1_consumers.err
   if [ $PART != extra_nopmc ]; then bash tools/prof_counters.sh r05_c1_lone_wave --workload c1 > gpurun_out/r05_pmc_c1.log 2>&1; fi
   FSMC_HOST_TIMING=1 python3 tools/measure_configs.py run_c2 > gpurun_out/round_r05/run_c2_timeline.json 2> gpurun_out/round_r05/run_c2_timeline.err
+  python3 tools/measure_configs.py run_c1_asmc > gpurun_out/round_r05/run_c1_asmc.jsonl 2> gpurun_out/round_r05/run_c1_asmc.err
   python3 tools/malloc_cost.py > gpurun_out/round_r05/malloc_cost.txt 2>&1
   python3 bench.py --workload c1 --mode sums --steps 10 --warmup 2 --cpu-pairs 0 > gpurun_out/round_r05/c1_sums_bench.json 2> gpurun_out/round_r05/c1_sums_bench.err
   echo "extra done"
