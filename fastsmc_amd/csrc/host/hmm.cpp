@@ -460,15 +460,117 @@ bool isRegularFile(const std::string& path)
   return ::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
 }
 
+namespace
+{
+// gzopen(name, mode) that also hands out the descriptor
+gzFile gzOpenWithFd(const std::string& name, const char* mode, int& fd)
+{
+  fd = ::open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) {
+    return nullptr;
+  }
+  gzFile f = gzdopen(fd, mode);
+  if (!f) {
+    ::close(fd);
+    fd = -1;
+  }
+  return f;
+}
+
+// one complete gzip member holding `n` bytes, at zlib's default level (what gzopen(name, "w") writes with)
+std::string gzipMember(const char* data, size_t n)
+{
+  z_stream z{};
+  if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+    throw std::runtime_error("deflateInit2 failed");
+  }
+  std::string out(deflateBound(&z, static_cast<uLong>(n)) + 32, '\0');
+  z.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(data));
+  z.avail_in = static_cast<uInt>(n);
+  z.next_out = reinterpret_cast<Bytef*>(&out[0]);
+  z.avail_out = static_cast<uInt>(out.size());
+  const int rc = deflate(&z, Z_FINISH);
+  const size_t have = out.size() - z.avail_out;
+  deflateEnd(&z);
+  if (rc != Z_STREAM_END) {
+    throw std::runtime_error("deflate failed");
+  }
+  out.resize(have);
+  return out;
+}
+
+// threads that format / compress a flush's output (FSMC_HOST_OUTPUT_THREADS=1 in the environment: the one-thread path,
+// for A/B timings)
+size_t outputThreads()
+{
+  static const size_t n = [] {
+    if (const char* v = std::getenv("FSMC_HOST_OUTPUT_THREADS")) {
+      const int t = std::atoi(v);
+      if (t >= 1) {
+        return static_cast<size_t>(t);
+      }
+    }
+    return static_cast<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+  }();
+  return n;
+}
+
+void writeAll(int fd, const std::string& bytes)
+{
+  size_t off = 0;
+  while (off < bytes.size()) {
+    const ssize_t w = ::write(fd, bytes.data() + off, bytes.size() - off);
+    if (w < 0) {
+      throw std::runtime_error("cannot write the output file");
+    }
+    off += static_cast<size_t>(w);
+  }
+}
+
+// A flush's text into the IBD file.  Small: gzwrite.  Large: the text is cut at line ends into pieces that several
+// threads compress into gzip members of their own, which go to the file behind the member gzwrite had under way (a gzip
+// file is a sequence of members; zlib, zcat, Python's gzip and java.util.zip read them as one stream) -- the text a reader
+// sees is the same, and deflate, two thirds of what the C2 job's 20 000 records cost after the kernel, runs in parallel.
+void putIbdText(gzFile file, int fd, const std::string& text)
+{
+  const size_t piece = (size_t)128 << 10;
+  const size_t nThreads = std::min<size_t>(outputThreads(), text.size() / piece);
+  if (fd < 0 || nThreads < 2) {
+    for (size_t off = 0; off < text.size(); off += (size_t)1 << 30) {
+      gzwrite(file, text.data() + off, static_cast<unsigned>(std::min<size_t>(text.size() - off, (size_t)1 << 30)));
+    }
+    return;
+  }
+  std::vector<size_t> cut(nThreads + 1, text.size());
+  cut[0] = 0;
+  for (size_t t = 1; t < nThreads; ++t) {
+    const size_t at = text.find('\n', text.size() * t / nThreads);
+    cut[t] = at == std::string::npos ? text.size() : at + 1;
+  }
+  std::vector<std::future<std::string>> members;
+  for (size_t t = 0; t < nThreads; ++t) {
+    members.push_back(std::async(std::launch::async, [&text, &cut, t] {
+      return cut[t + 1] > cut[t] ? gzipMember(text.data() + cut[t], cut[t + 1] - cut[t]) : std::string();
+    }));
+  }
+  gzflush(file, Z_FINISH); // the member under way ends here; a later gzwrite starts a new one
+  for (auto& m : members) {
+    writeAll(fd, m.get());
+  }
+}
+} // namespace
+
 void HMM::closePerPairFiles()
 {
   if (mMeanFile) {
     gzclose(mMeanFile);
     mMeanFile = nullptr;
+    mMeanFd = -1;
   }
   if (mMapFile) {
     gzclose(mMapFile);
     mMapFile = nullptr;
+    mMapFd = -1;
   }
 }
 
@@ -525,19 +627,19 @@ void HMM::resetDecoding()
   // HMM.cpp:259-271: the per-pair text outputs of ASMC mode are (re)opened here
   closePerPairFiles();
   mPerPairRows = 0;
-  auto openOut = [&](const std::string& suffix) {
+  auto openOut = [&](const std::string& suffix, int& fd) {
     const std::string name = mParams.outFileRoot + suffix;
-    gzFile f = gzopen(name.c_str(), "w");
+    gzFile f = gzOpenWithFd(name, "w", fd);
     if (!f) {
       throw std::runtime_error("ERROR: could not open " + name);
     }
     return f;
   };
   if (mWriteMean && !mParams.FastSMC) {
-    mMeanFile = openOut(".perPairPosteriorMeans.gz");
+    mMeanFile = openOut(".perPairPosteriorMeans.gz", mMeanFd);
   }
   if (mWriteMap && !mParams.FastSMC) {
-    mMapFile = openOut(".perPairMAP.gz");
+    mMapFile = openOut(".perPairMAP.gz", mMapFd);
   }
   const size_t n = static_cast<size_t>(mData.sites) * mDq.states;
   mReturn.sumOverPairs.assign(n, 0.f);
@@ -886,11 +988,12 @@ void HMM::flush()
       // max_digits10 = 9 there: FSMC_EIGEN_FULL_PRECISION_DIGITS=9 in the environment writes the file such a build of
       // the reference writes.
       const auto B = static_cast<uint64_t>(mBatchSize);
-      std::string text;
-      char buf[48];
-      auto writeRows = [&](gzFile f, auto&& cell) {
-        text.clear();
-        for (size_t i = 0; i < nPairs; ++i) {
+      // the rows of pairs [lo, hi) as text (the newline rule above counts rows over the whole file)
+      auto rowsText = [&](size_t lo, size_t hi, auto&& cell) {
+        std::string text;
+        text.reserve((hi - lo) * S * 8);
+        char buf[48];
+        for (size_t i = lo; i < hi; ++i) {
           if ((mPerPairRows + i) % B != 0) {
             text.push_back('\n');
           }
@@ -900,12 +1003,38 @@ void HMM::flush()
             }
             text.append(buf, static_cast<size_t>(cell(buf, sizeof(buf), i * S + pos)));
           }
-          if (text.size() > (1u << 22)) {
+        }
+        return text;
+      };
+      // A few rows: one thread, gzwrite.  Many (a number per pair and site: 300 million for the reference's example
+      // cohort): several threads format AND compress blocks of rows into gzip members of their own, written in order
+      // behind whatever gzwrite had under way (putIbdText, above: one stream to every reader of gzip files).
+      auto writeRows = [&](gzFile f, int fd, auto&& cell) {
+        const size_t rowsPerThread = std::max<size_t>(1, ((size_t)1 << 20) / (S * 8 + 1)); // (about a MiB of text a piece)
+        const size_t nThreads = std::min<size_t>(outputThreads(), (nPairs + rowsPerThread - 1) / rowsPerThread);
+        if (fd < 0 || nThreads < 2) {
+          for (size_t lo = 0; lo < nPairs; lo += rowsPerThread) {
+            const std::string text = rowsText(lo, std::min(nPairs, lo + rowsPerThread), cell);
             gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
-            text.clear();
+          }
+          return;
+        }
+        gzflush(f, Z_FINISH);
+        for (size_t blockLo = 0; blockLo < nPairs; blockLo += nThreads * rowsPerThread) {
+          std::vector<std::future<std::string>> members;
+          for (size_t t = 0; t < nThreads; ++t) {
+            const size_t lo = std::min(nPairs, blockLo + t * rowsPerThread), hi = std::min(nPairs, lo + rowsPerThread);
+            if (lo < hi) {
+              members.push_back(std::async(std::launch::async, [&, lo, hi] {
+                const std::string text = rowsText(lo, hi, cell);
+                return gzipMember(text.data(), text.size());
+              }));
+            }
+          }
+          for (auto& m : members) {
+            writeAll(fd, m.get());
           }
         }
-        gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
       };
       if (mMeanFile) {
         int digits = 6;
@@ -916,12 +1045,12 @@ void HMM::flush()
           }
           digits = d;
         }
-        writeRows(mMeanFile, [&](char* b, size_t n, size_t idx) {
+        writeRows(mMeanFile, mMeanFd, [&](char* b, size_t n, size_t idx) {
           return std::snprintf(b, n, "%.*g", digits, static_cast<double>(mean[idx]));
         });
       }
       if (mMapFile) {
-        writeRows(mMapFile, [&](char* b, size_t n, size_t idx) { return std::snprintf(b, n, "%d", map[idx]); });
+        writeRows(mMapFile, mMapFd, [&](char* b, size_t n, size_t idx) { return std::snprintf(b, n, "%d", map[idx]); });
       }
       mPerPairRows += nPairs;
     }
@@ -977,87 +1106,6 @@ std::string HMM::ibdFileName(int jobs, int jobInd) const
   }
   return name;
 }
-
-namespace
-{
-// gzopen(name, mode) that also hands out the descriptor
-gzFile gzOpenWithFd(const std::string& name, const char* mode, int& fd)
-{
-  fd = ::open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-  if (fd < 0) {
-    return nullptr;
-  }
-  gzFile f = gzdopen(fd, mode);
-  if (!f) {
-    ::close(fd);
-    fd = -1;
-  }
-  return f;
-}
-
-// one complete gzip member holding `n` bytes, at zlib's default level (what gzopen(name, "w") writes with)
-std::string gzipMember(const char* data, size_t n)
-{
-  z_stream z{};
-  if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
-    throw std::runtime_error("deflateInit2 failed");
-  }
-  std::string out(deflateBound(&z, static_cast<uLong>(n)) + 32, '\0');
-  z.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(data));
-  z.avail_in = static_cast<uInt>(n);
-  z.next_out = reinterpret_cast<Bytef*>(&out[0]);
-  z.avail_out = static_cast<uInt>(out.size());
-  const int rc = deflate(&z, Z_FINISH);
-  const size_t have = out.size() - z.avail_out;
-  deflateEnd(&z);
-  if (rc != Z_STREAM_END) {
-    throw std::runtime_error("deflate failed");
-  }
-  out.resize(have);
-  return out;
-}
-
-// A flush's text into the IBD file.  Small: gzwrite.  Large: the text is cut at line ends into pieces that several
-// threads compress into gzip members of their own, which go to the file behind the member gzwrite had under way (a gzip
-// file is a sequence of members; zlib, zcat, Python's gzip and java.util.zip read them as one stream) -- the text a reader
-// sees is the same, and deflate, two thirds of what the C2 job's 20 000 records cost after the kernel, runs in parallel.
-void putIbdText(gzFile file, int fd, const std::string& text)
-{
-  const size_t piece = (size_t)128 << 10;
-  const size_t nThreads =
-      std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16, text.size() / piece});
-  if (fd < 0 || nThreads < 2) {
-    for (size_t off = 0; off < text.size(); off += (size_t)1 << 30) {
-      gzwrite(file, text.data() + off, static_cast<unsigned>(std::min<size_t>(text.size() - off, (size_t)1 << 30)));
-    }
-    return;
-  }
-  std::vector<size_t> cut(nThreads + 1, text.size());
-  cut[0] = 0;
-  for (size_t t = 1; t < nThreads; ++t) {
-    const size_t at = text.find('\n', text.size() * t / nThreads);
-    cut[t] = at == std::string::npos ? text.size() : at + 1;
-  }
-  std::vector<std::future<std::string>> members;
-  for (size_t t = 0; t < nThreads; ++t) {
-    members.push_back(std::async(std::launch::async, [&text, &cut, t] {
-      return cut[t + 1] > cut[t] ? gzipMember(text.data() + cut[t], cut[t + 1] - cut[t]) : std::string();
-    }));
-  }
-  gzflush(file, Z_FINISH); // the member under way ends here; a later gzwrite starts a new one
-  for (auto& m : members) {
-    const std::string bytes = m.get();
-    size_t off = 0;
-    while (off < bytes.size()) {
-      const ssize_t w = ::write(fd, bytes.data() + off, bytes.size() - off);
-      if (w < 0) {
-        throw std::runtime_error("cannot write the IBD output file");
-      }
-      off += static_cast<size_t>(w);
-    }
-  }
-}
-} // namespace
 
 void HMM::openIbdFile(int jobs, int jobInd)
 {
@@ -1324,7 +1372,7 @@ std::string HMM::formatIbdRecords(const fsmc_pair* pairs, const fsmc_ibd_record*
     return text.str();
   };
   const size_t perThread = 256;
-  const size_t nThreads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16, n / perThread});
+  const size_t nThreads = std::min<size_t>(outputThreads(), n / perThread);
   if (nThreads < 2) {
     return part(0, n);
   }

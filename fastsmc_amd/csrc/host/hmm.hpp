@@ -229,6 +229,7 @@ private:
   bool mStoreMean = false, mStoreMap = false, mStorePosterior = false, mStoreSumOfPosterior = false;
   bool mWriteMean = false, mWriteMap = false;
   gzFile mMeanFile = nullptr, mMapFile = nullptr;
+  int mMeanFd = -1, mMapFd = -1; // their descriptors (blocks of rows go out as gzip members of their own)
   uint64_t mPerPairRows = 0; // rows written to the per-pair files since they were opened (batch boundaries)
   void closePerPairFiles();
   bool mKeepRecords = false;
